@@ -1,0 +1,80 @@
+"""ctypes binding of libbidate_hip.so (C ABI: include/bidate_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbidate_hip.so')
+
+BDN_F32, BDN_BF16 = 0, 1
+IN_PLAIN, IN_BNRELU = 0, 1
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/bidate_hip.h one to one
+SIGNATURES = {
+    'bdn_last_error': (C.c_char_p, []),
+    'bdn_version': (_i, []),
+    'bdn_pack_input': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_pack_weights': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'bdn_conv3x3': (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_conv3x3_num_mtiles': (_i, [_i, _i, _i, _i]),
+    'bdn_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'bdn_conv3x3_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
+    'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'bdn_upsample2x_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_outc_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_outc_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_sgd_step': (_i, [_vp, _vp, _f, _f, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'fabric_amd: HIP extension {LIB_PATH} not found. Build it with '
+            f'`python -c "import __graft_entry__ as g; g.build()"` or `make -C fabric_amd/csrc`. '
+            f'There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.bdn_last_error().decode(errors='replace')
+        raise RuntimeError(f'{name} failed (rc={rc}): {msg}')
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,135 @@
+// Shared device/host helpers for libbidate_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/bidate_hip.h"
+
+typedef uint16_t bf16s;                                   // bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ---------------------------------------------------------------- errors
+void bdn_set_error(const char* fmt, ...);
+#define BDN_FAIL(code, ...) do { bdn_set_error(__VA_ARGS__); return (code); } while (0)
+#define BDN_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) BDN_FAIL(BDN_E_HIP, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------- element traits
+template <typename T> struct ET;
+template <> struct ET<float> { static constexpr int EPU = 4; };   // elements per 16-byte unit
+template <> struct ET<bf16s> { static constexpr int EPU = 8; };
+
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {            // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16s v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16s from_f<bf16s>(float v) { return (bf16s)f2bf(v); }
+
+// 16-byte unit <-> float[EPU]
+template <typename T> struct Unit;
+template <> struct Unit<float> {
+    static constexpr int N = 4;
+    __device__ __forceinline__ static void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+        f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    __device__ __forceinline__ static uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Unit<bf16s> {
+    static constexpr int N = 8;
+    __device__ __forceinline__ static void unpack(const uint4& u, float* f) {
+        f[0] = bf2f(u.x & 0xffffu); f[1] = bf2f(u.x >> 16);
+        f[2] = bf2f(u.y & 0xffffu); f[3] = bf2f(u.y >> 16);
+        f[4] = bf2f(u.z & 0xffffu); f[5] = bf2f(u.z >> 16);
+        f[6] = bf2f(u.w & 0xffffu); f[7] = bf2f(u.w >> 16);
+    }
+    __device__ __forceinline__ static uint4 pack(const float* f) {
+        return make_uint4(f2bf(f[0]) | (f2bf(f[1]) << 16), f2bf(f[2]) | (f2bf(f[3]) << 16),
+                          f2bf(f[4]) | (f2bf(f[5]) << 16), f2bf(f[6]) | (f2bf(f[7]) << 16));
+    }
+};
+
+// BatchNorm table layout: bn[g][k][c], k = 0 mean, 1 invstd, 2 scale, 3 shift
+__device__ __forceinline__ const float* bn_row(const float* bn, int g, int k, int C) {
+    return bn + ((size_t)g * 4 + k) * C;
+}
+
+// relu(z*scale+shift) on one 16-byte unit; sc/sh point at the unit's first channel
+template <typename T>
+__device__ __forceinline__ uint4 bnrelu_unit(const uint4& u, const float* sc, const float* sh) {
+    constexpr int N = Unit<T>::N;
+    float f[N];
+    Unit<T>::unpack(u, f);
+#pragma unroll
+    for (int i = 0; i < N; i++) f[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
+    return Unit<T>::pack(f);
+}
+
+// XCD-aware bijective block remap: consecutive logical ids stay on one XCD (private L2)
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---------------------------------------------------------------- spatial tile geometry (shared by fwd/dgrad and wgrad)
+// A block covers TI images x TH x TW output pixels ("slots"); its input patch has a 1-pixel halo.
+template <int TH, int TW, int TI> struct Tile {
+    static constexpr int BM = TI * TH * TW;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int NPIX = TI * PH * PW;
+    __device__ __forceinline__ static int slot_to_pix(int s) {           // patch index of the slot's (r=0,c=0) tap
+        int ti = s / (TH * TW), rem = s % (TH * TW);
+        return (ti * PH + rem / TW) * PW + rem % TW;
+    }
+    __device__ __forceinline__ static void slot_to_nyx(int s, int& ti, int& py, int& px) {
+        ti = s / (TH * TW); int rem = s % (TH * TW); py = rem / TW; px = rem % TW;
+    }
+};
+
+struct TileGeom { int tiles_y, tiles_x, n_mtiles, TI, TH, TW; };
+static inline TileGeom pick_tile(int N, int H, int W, int imgs_per_group) {
+    TileGeom g;
+    if (W <= 8 && H <= 8 && imgs_per_group % 2 == 0) { g.TI = 2; g.TH = 8; g.TW = 8; }
+    else { g.TI = 1; g.TH = 8; g.TW = 16; }
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    g.n_mtiles = ((N + g.TI - 1) / g.TI) * g.tiles_y * g.tiles_x;
+    return g;
+}
+
+// Stage the input patch of one channel chunk into LDS (zero outside the image = conv zero padding).
+// CKB = bytes of channels per pixel in the chunk, PSTR = LDS pixel stride in bytes.
+// cvalid = number of valid channels in this chunk (others zero-filled); sc/sh: BN scale/shift rows
+// already offset to the chunk's first channel, or nullptr for plain input.
+template <typename T, int CKB, int PSTR, int TH, int TW, int TI>
+__device__ __forceinline__ void stage_patch(unsigned char* patch, const T* src, int Csrc, int cs, int cvalid,
+                                            const float* sc, const float* sh,
+                                            int n0, int y0, int x0, int N, int H, int W, int tid) {
+    using TL = Tile<TH, TW, TI>;
+    constexpr int EPU = ET<T>::EPU;
+    constexpr int UPP = CKB / 16;
+    for (int u = tid; u < TL::NPIX * UPP; u += 256) {
+        int pix = u / UPP, sub = u % UPP;
+        int xx = pix % TL::PW; int t = pix / TL::PW; int yy = t % TL::PH; int ti = t / TL::PH;
+        int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n < N && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && sub * EPU < cvalid) {
+            const T* p = src + ((size_t)(n * H + y) * W + x) * Csrc + cs + sub * EPU;
+            v = *reinterpret_cast<const uint4*>(p);
+            if (sc) v = bnrelu_unit<T>(v, sc + sub * EPU, sh + sub * EPU);
+        }
+        *reinterpret_cast<uint4*>(patch + pix * PSTR + sub * 16) = v;
+    }
+}

@@ -1,0 +1,232 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution (autograd of reference
+// models/unet_parts.py:13,16) as an implicit GEMM whose reduction runs over output PIXELS:
+//
+//   dW[co][tap][ci] = sum_{n,y,x} dz[n,y,x,co] * a[n, y+r-1, x+c-1, ci]        tap = 3r+c
+//
+// One 256-thread block owns a 64(co) x 64(ci) tile for ALL nine taps (9 x 32x32 accumulators per
+// wave) and a contiguous range of 128-pixel spatial chunks (split over pixels; partial tiles are
+// written to a workspace and summed by wgrad_reduce_kernel, which also emits the reference's
+// OIHW f32 layout -- deterministic, no atomics).
+// Per chunk the dz tile [128 px][64 co] and the activation halo patch [(8+2)x(16+2) px][64 ci]
+// are staged into LDS in their natural NHWC order; the MFMA operands need 8 consecutive *pixels*
+// per lane, which on gfx950 is exactly what ds_read_b64_tr_b16 delivers from a channel-minor
+// image (lane-group semantics pinned by tools/probe_hw.hip): no transposed copy ever exists.
+// The f32 variant feeds v_mfma_f32_32x32x2_f32, whose one-value-per-lane operands are plain
+// conflict-free ds_read_b32.
+#include "common.hpp"
+
+struct WgradArgs {
+    const void* dz; int Cout;
+    const void* in0; const void* in1; int C0, C1;
+    const float* in_bn; int imgs_per_group;
+    float* partial;                // [S][9][Cout][Cin]
+    int N, H, W;
+    int tiles_y, tiles_x, n_mtiles;
+    int S, per_split, n_cot, n_cit;
+};
+
+template <typename T, int TH, int TW, int TI>
+struct WgCfg {
+    using TL = Tile<TH, TW, TI>;
+    static constexpr int ES = sizeof(T);
+    static constexpr int CKB = 64 * ES;                 // 64 channels per operand row
+    static constexpr int STR = CKB + 64;                // LDS pixel stride: 192 B (bf16) keeps the 4 pixel rows a
+                                                        // transposing read touches on disjoint banks
+    static constexpr int PATCH_BYTES = TL::NPIX * STR;
+    static constexpr int DZ_BYTES = TL::BM * STR;
+    static constexpr int SMEM = PATCH_BYTES + DZ_BYTES;
+};
+
+__device__ __forceinline__ uint4 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+template <typename T, int TH, int TW, int TI>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    using CF = WgCfg<T, TH, TW, TI>;
+    using TL = typename CF::TL;
+    constexpr int STR = CF::STR, EPU = ET<T>::EPU, UPP = CF::CKB / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch = smem;
+    unsigned char* dzt = smem + CF::PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;             // wave tile: co [wm*32,+32) x ci [wn*32,+32)
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.n_cot * a.n_cit;
+    const int tile = logical % ntile, split = logical / ntile;
+    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
+    const int Cin = a.C0 + a.C1;
+
+    const T* src; int Csrc, cs; bool use_bn = false;
+    if (ci0 < a.C0) { src = reinterpret_cast<const T*>(a.in0); Csrc = a.C0; cs = ci0; use_bn = a.in_bn != nullptr; }
+    else { src = reinterpret_cast<const T*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
+    const int cvalid = min(64, Csrc - cs);
+    const T* dzp = reinterpret_cast<const T*>(a.dz);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    for (int q = q_begin; q < q_end; q++) {
+        const int tx = q % a.tiles_x, ty = (q / a.tiles_x) % a.tiles_y, ib = q / (a.tiles_x * a.tiles_y);
+        const int n0 = ib * TI, y0 = ty * TH, x0 = tx * TW;
+        const int grp = n0 / a.imgs_per_group;
+        const float* sc = use_bn ? bn_row(a.in_bn, grp, 2, a.C0) + cs : nullptr;
+        const float* sh = use_bn ? bn_row(a.in_bn, grp, 3, a.C0) + cs : nullptr;
+        __syncthreads();                                   // previous chunk's reads are done
+        stage_patch<T, CF::CKB, STR, TH, TW, TI>(patch, src, Csrc, cs, cvalid, sc, sh, n0, y0, x0, a.N, a.H, a.W, tid);
+        for (int u = tid; u < TL::BM * UPP; u += 256) {   // dz tile, zero for slots outside the image
+            const int slot = u / UPP, sub = u % UPP;
+            int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
+            const int n = n0 + ti, y = y0 + py, x = x0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n < a.N && y < a.H && x < a.W)
+                v = *reinterpret_cast<const uint4*>(dzp + ((size_t)(n * a.H + y) * a.W + x) * a.Cout + co0 + sub * EPU);
+            *reinterpret_cast<uint4*>(dzt + slot * STR + sub * 16) = v;
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 2) {
+            // lane's transposing-read role: pixel (lane&15)>>2 of a 4-pixel group, 4-channel piece (lane&3)
+            // of the 16-channel block ((lane>>4)&1) of this wave's 32 channels
+            const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+            const int kpix = (lane & 15) >> 2;
+#pragma unroll 2
+            for (int ks = 0; ks < TL::BM / 16; ks++) {
+                const int s0 = ks * 16 + half * 8 + kpix;            // k = 8*half + [0,4) ; +4 for the second read
+                const uint4 af = tr_pair(dzt + s0 * STR + wm * 64 + chan_b, dzt + (s0 + 4) * STR + wm * 64 + chan_b);
+                const unsigned char* pb0 = patch + TL::slot_to_pix(s0) * STR + wn * 64 + chan_b;
+                const unsigned char* pb1 = patch + TL::slot_to_pix(s0 + 4) * STR + wn * 64 + chan_b;
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    const int tapoff = ((tap / 3) * TL::PW + (tap % 3)) * STR;
+                    const uint4 bfr = tr_pair(pb0 + tapoff, pb1 + tapoff);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                                       __builtin_bit_cast(bf16x8, bfr), acc[tap], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int ks = 0; ks < TL::BM / 2; ks++) {
+                const int s = ks * 2 + half;
+                const float av = *reinterpret_cast<const float*>(dzt + s * STR + (wm * 32 + l31) * 4);
+                const unsigned char* pb = patch + TL::slot_to_pix(s) * STR + (wn * 32 + l31) * 4;
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    const int tapoff = ((tap / 3) * TL::PW + (tap % 3)) * STR;
+                    const float bv = *reinterpret_cast<const float*>(pb + tapoff);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // partial[split][tap][co][ci]
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                a.partial[(((size_t)split * 9 + tap) * a.Cout + co) * Cin + ci] = acc[tap][r];
+            }
+    }
+}
+
+// dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                    int S, int Cout, int Cin, int Cin_real) {
+    const size_t total = (size_t)9 * Cout * Cin;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = i % Cin; const size_t t = i / Cin; const int co = t % Cout; const int tap = t / Cout;
+    if (ci >= Cin_real) return;
+    float s = 0.f;
+    for (int k = 0; k < S; k++) s += partial[(size_t)k * total + i];
+    dw[((size_t)co * Cin_real + ci) * 9 + tap] = s;
+}
+
+struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; };
+static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
+    WgPlan p;
+    p.g = pick_tile(N, H, W, imgs_per_group);
+    p.n_cot = Cout / 64;
+    p.n_cit = (Cin + 63) / 64;
+    const int tiles = p.n_cot * p.n_cit;
+    int S = (1024 + tiles - 1) / tiles;                     // aim at ~1024 blocks (4 per CU)
+    if (S > p.g.n_mtiles) S = p.g.n_mtiles;
+    if (S < 1) S = 1;
+    p.per_split = (p.g.n_mtiles + S - 1) / S;
+    p.S = (p.g.n_mtiles + p.per_split - 1) / p.per_split;   // no empty splits
+    return p;
+}
+
+extern "C" size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || imgs_per_group <= 0) return 0;
+    WgPlan p = wgrad_plan(N, H, W, Cout, Cin, imgs_per_group);
+    return (size_t)p.S * 9 * Cout * Cin * sizeof(float);
+}
+
+template <typename T, int TH, int TW, int TI>
+static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    using CF = WgCfg<T, TH, TW, TI>;
+    auto kern = wgrad_kernel<T, TH, TW, TI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", CF::SMEM, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), CF::SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad");
+    return BDN_OK;
+}
+
+extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
+                                 const void* in0, int C0, const void* in1, int C1,
+                                 int in_mode, const float* in_bn, int imgs_per_group,
+                                 float* partial, float* dw_oihw, int Cin_real,
+                                 int N, int H, int W, void* stream) {
+    if (!dz || !in0 || !partial || !dw_oihw) BDN_FAIL(BDN_E_ARG, "wgrad: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
+        BDN_FAIL(BDN_E_SHAPE, "wgrad: bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
+    if (Cout <= 0 || Cout % 64) BDN_FAIL(BDN_E_SHAPE, "wgrad: Cout=%d must be a multiple of 64", Cout);
+    if (in1 == nullptr) C1 = 0;
+    if (C0 <= 0 || C0 % 16 || C1 % 64 || (in1 && C0 % 64))
+        BDN_FAIL(BDN_E_SHAPE, "wgrad: C0=%d must be a multiple of 16 (64 with a second source), C1=%d of 64", C0, C1);
+    if (in_mode == BDN_IN_BNRELU && (!in_bn || in1)) BDN_FAIL(BDN_E_ARG, "wgrad: BNRELU input needs in_bn and a single source");
+    const int Cin = C0 + C1;
+    if (Cin_real <= 0 || Cin_real > Cin) BDN_FAIL(BDN_E_SHAPE, "wgrad: Cin_real=%d out of range", Cin_real);
+    WgPlan p = wgrad_plan(N, H, W, Cout, Cin, imgs_per_group);
+    WgradArgs a;
+    a.dz = dz; a.Cout = Cout; a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
+    a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr; a.imgs_per_group = imgs_per_group;
+    a.partial = partial; a.N = N; a.H = H; a.W = W;
+    a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles;
+    a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (dtype == BDN_BF16) {
+        rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1>(a, st) : launch_wgrad<bf16s, 8, 8, 2>(a, st);
+    } else if (dtype == BDN_F32) {
+        rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1>(a, st) : launch_wgrad<float, 8, 8, 2>(a, st);
+    } else BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
+    if (rc) return rc;
+    const size_t total = (size_t)9 * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       partial, dw_oihw, p.S, Cout, Cin, Cin_real);
+    BDN_CHECK_LAUNCH("wgrad_reduce");
+    return BDN_OK;
+}

@@ -1,0 +1,337 @@
+"""Host-side schedule of the bi-date Siamese U-Net on the HIP kernels.
+
+This is the layer between the drop-in module surface (fabric_amd/models) and the
+C ABI (include/bidate_hip.h): it owns the NHWC workspaces (torch tensors = caller
+owned device memory), the packed-weight cache, and the order in which the fused
+stages are enqueued on the current HIP stream.  It mirrors the data flow of the
+reference's BiDateNet.forward (models/bidate_model.py:22-40) and of autograd through
+it, with three structural differences chosen for the hardware:
+
+  * both dates go through the shared encoder as ONE batch of 2B images with two
+    BatchNorm statistic groups (the reference calls the encoder twice);
+  * BatchNorm+ReLU is never materialised for 3x3-conv consumers: the consumer
+    applies relu(z*scale+shift) while staging its input tile;
+  * torch.cat of the skip and the upsampled map is never materialised: the decoder
+    convolutions walk two source tensors along K.
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+from ._lib import BDN_BF16, BDN_F32, IN_BNRELU, IN_PLAIN, call, ptr
+
+ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
+DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class ConvLayer:
+    name: str            # short id: e1a, e1b, ..., d4b
+    conv: str            # state-dict prefix of the nn.Conv2d
+    bn: str              # state-dict prefix of the nn.BatchNorm2d that follows
+    cin_real: int
+    cin: int             # padded to the kernel's channel granule
+    cout: int
+    level: int           # spatial level 1..5
+    enc: bool
+
+
+def build_layers(n_channels):
+    """The 18 3x3 convolutions in forward order with their reference state-dict keys."""
+    layers = []
+    cp = _round_up(n_channels, 16)
+    prev_real, prev = n_channels, cp
+    for k in range(1, 6):
+        base = 'inc.conv.conv' if k == 1 else f'down{k - 1}.mpconv.1.conv'
+        co = ENC_CH[k - 1]
+        layers.append(ConvLayer(f'e{k}a', f'{base}.0', f'{base}.1', prev_real, prev, co, k, True))
+        layers.append(ConvLayer(f'e{k}b', f'{base}.3', f'{base}.4', co, co, co, k, True))
+        prev_real = prev = co
+    cprev = ENC_CH[4]
+    for j in range(1, 5):
+        k = 5 - j
+        base = f'up{j}.conv.conv'
+        ci = ENC_CH[k - 1] + cprev
+        co = DEC_OUT[j - 1]
+        layers.append(ConvLayer(f'd{j}a', f'{base}.0', f'{base}.1', ci, ci, co, k, False))
+        layers.append(ConvLayer(f'd{j}b', f'{base}.3', f'{base}.4', co, co, co, k, False))
+        cprev = co
+    return layers
+
+
+def param_order(n_channels):
+    """State-dict keys of all learnable tensors in the order their gradients complete during
+    backward (decoder top first, `inc` last); conv biases that feed a BatchNorm (analytically zero
+    gradient) go last.  Used to lay out the flat gradient / parameter buffers so that gradient
+    all-reduce buckets are contiguous slices that become ready front to back."""
+    layers = build_layers(n_channels)
+    order = ['outc.conv.weight', 'outc.conv.bias']
+    for L in reversed(layers):
+        order += [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight']
+    order += [f'{L.conv}.bias' for L in reversed(layers)]
+    return order
+
+
+class Workspace:
+    """All device buffers for one (B, H, W) problem shape."""
+
+    def __init__(self, eng, B, H, W, device):
+        self.B, self.H, self.W = B, H, W
+        td = eng.tdtype
+        self.dims = []
+        h, w = H, W
+        for k in range(5):
+            self.dims.append((h, w))
+            h, w = h // 2, w // 2
+        if min(self.dims[4]) < 1:
+            raise RuntimeError(f'BiDateNet needs H,W >= 16 (got {H}x{W}): four 2x poolings')
+        e = lambda *s: torch.empty(*s, dtype=td, device=device)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.x0 = e(2 * B, H, W, eng.cp)
+        self.z, self.bn, self.pool, self.f, self.U = {}, {}, {}, {}, {}
+        for L in eng.layers:
+            hk, wk = self.dims[L.level - 1]
+            n = 2 * B if L.enc else B
+            self.z[L.name] = e(n, hk, wk, L.cout)
+            self.bn[L.name] = f32(2 if L.enc else 1, 4, L.cout)
+        for k in range(1, 6):
+            hk, wk = self.dims[k - 1]
+            if k >= 2:
+                self.pool[k] = e(2 * B, hk, wk, ENC_CH[k - 2])
+            self.f[k] = e(B, hk, wk, ENC_CH[k - 1])
+        cprev = ENC_CH[4]
+        for j in range(1, 5):
+            hk, wk = self.dims[4 - j]
+            self.U[j] = e(B, hk, wk, cprev)
+            cprev = DEC_OUT[j - 1]
+        lib = _lib.load()
+        n_stats = n_bnb = n_wg = 1
+        for L in eng.layers:
+            hk, wk = self.dims[L.level - 1]
+            n, ipg = (2 * B, B) if L.enc else (B, B)
+            n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, ipg) * 2 * L.cout)
+            n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(n, hk, wk, L.cout) // 4)
+            n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes(n, hk, wk, L.cout, L.cin, ipg) // 4)
+        self.stats = f32(n_stats)
+        self.n_bnb, self.n_wg = n_bnb, n_wg
+        self._bwd = None
+        self.logits = None
+
+    def bwd_scratch(self, device):
+        if self._bwd is None:
+            self._bwd = dict(bnb=torch.empty(self.n_bnb, dtype=torch.float32, device=device),
+                             wg=torch.empty(self.n_wg, dtype=torch.float32, device=device),
+                             sums=torch.empty(2 * 2 * 1024, dtype=torch.float32, device=device))
+        return self._bwd
+
+
+class BiDateEngine:
+    """Enqueues forward / backward of BiDateNet(n_channels, n_classes) on the HIP library.
+
+    precision: 'bf16' (bf16 activations and packed weights, fp32 accumulate -- throughput setting) or
+    'fp32' (f32 storage + f32 MFMA -- the 1e-3 parity setting).  Same kernels, one template parameter."""
+
+    def __init__(self, n_channels, n_classes, precision='bf16'):
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        self.n_channels, self.n_classes = n_channels, n_classes
+        self.precision = precision
+        self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32
+        self.tdtype = torch.bfloat16 if precision == 'bf16' else torch.float32
+        self.esize = 2 if precision == 'bf16' else 4
+        self.cp = _round_up(n_channels, 16)
+        self.layers = build_layers(n_channels)
+        self._ws = {}
+        self._packed = {}          # conv prefix -> (version key, wf, wd)
+        _lib.load()                # fail loudly now if the HIP extension is missing
+
+    # ------------------------------------------------------------------ helpers
+    def workspace(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in self._ws:
+            self._ws[key] = Workspace(self, B, H, W, device)
+        return self._ws[key]
+
+    def _weights(self, L, P, need_wd):
+        w = P[f'{L.conv}.weight']
+        key = (w.data_ptr(), w._version, str(w.device))
+        ent = self._packed.get(L.conv)
+        if ent is None or ent[0] != key:
+            wf = torch.empty(L.cout, 9, L.cin, dtype=self.tdtype, device=w.device)
+            wd = torch.empty(L.cin, 9, L.cout, dtype=self.tdtype, device=w.device) if L.name != 'e1a' else None
+            call('bdn_pack_weights', self.dt, ptr(w), ptr(wf), ptr(wd), L.cout, L.cin_real, L.cin, _lib.stream_ptr())
+            ent = (key, wf, wd)
+            self._packed[L.conv] = ent
+        return ent[1], ent[2]
+
+    def invalidate_weights(self):
+        self._packed.clear()
+
+    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st):
+        hk, wk = ws.dims[L.level - 1]
+        wf, _ = self._weights(L, P, False)
+        z = ws.z[L.name]
+        call('bdn_conv3x3', self.dt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
+             ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
+             n, hk, wk, L.cout, st)
+        bn = ws.bn[L.name]
+        G = n // ipg
+        if training:
+            nt = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, ipg)
+            call('bdn_bn_finalize', ptr(ws.stats), nt, G, L.cout, ipg * hk * wk,
+                 ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']), BN_EPS, BN_MOMENTUM,
+                 ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']),
+                 ptr(P[f'{L.bn}.num_batches_tracked']), ptr(bn), st)
+        else:
+            call('bdn_bn_eval', ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']),
+                 ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']), BN_EPS, G, L.cout, ptr(bn), st)
+        return z, bn
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x_d1, x_d2, P, training=True):
+        """x_d1, x_d2: [B,C,H,W] float32 CUDA tensors (reference layout).  P: state-dict-keyed tensors.
+        Returns (logits [B,n_classes,H,W] float32, workspace)."""
+        if not (x_d1.is_cuda and x_d2.is_cuda):
+            raise RuntimeError('fabric_amd: BiDateNet runs only on a ROCm device (MI355X); '
+                               'inputs must be CUDA/HIP tensors -- there is no CPU path')
+        if x_d1.shape != x_d2.shape or x_d1.dim() != 4 or x_d1.shape[1] != self.n_channels:
+            raise RuntimeError(f'expected two [B,{self.n_channels},H,W] tensors, got {tuple(x_d1.shape)} and {tuple(x_d2.shape)}')
+        x_d1 = x_d1.contiguous().float()
+        x_d2 = x_d2.contiguous().float()
+        B, C, H, W = x_d1.shape
+        dev = x_d1.device
+        ws = self.workspace(B, H, W, dev)
+        st = _lib.stream_ptr()
+        by = {L.name: L for L in self.layers}
+        call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, st)
+        # ---- shared encoder on both dates (2B images, 2 statistic groups)
+        for k in range(1, 6):
+            hk, wk = ws.dims[k - 1]
+            La, Lb = by[f'e{k}a'], by[f'e{k}b']
+            if k == 1:
+                src = ws.x0
+            else:
+                hp, wp = ws.dims[k - 2]
+                call('bdn_bnrelu_pool', self.dt, ptr(ws.z[f'e{k - 1}b']), ptr(ws.bn[f'e{k - 1}b']), B,
+                     ptr(ws.pool[k]), 2 * B, hp, wp, ENC_CH[k - 2], st)
+                src = ws.pool[k]
+            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st)
+            zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st)
+            call('bdn_fuse_product', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], st)
+        # ---- decoder on the fused skips
+        prev, prev_bn, prev_mode, cprev = ws.f[5], None, IN_PLAIN, ENC_CH[4]
+        for j in range(1, 5):
+            k = 5 - j
+            hk, wk = ws.dims[k - 1]
+            hs, wsrc = ws.dims[k]
+            La, Lb = by[f'd{j}a'], by[f'd{j}b']
+            call('bdn_upsample2x', self.dt, ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.U[j]),
+                 B, hs, wsrc, hk, wk, cprev, st)
+            za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st)
+            zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st)
+            prev, prev_bn, prev_mode, cprev = zb, bnb, IN_BNRELU, Lb.cout
+        logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)
+        call('bdn_outc_fwd', self.dt, ptr(prev), ptr(prev_bn), ptr(P['outc.conv.weight']), ptr(P['outc.conv.bias']),
+             ptr(logits), B, H, W, cprev, self.n_classes, st)
+        return logits, ws
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ws, dlogits, P, grads, on_ready=None):
+        """Gradient of the last training-mode forward on `ws`.
+
+        dlogits: [B,n_classes,H,W] float32.  grads: dict key -> preallocated float32 tensor (reference
+        parameter shapes) that is OVERWRITTEN.  on_ready(keys) is called after the kernels producing
+        those gradients have been enqueued (used to launch gradient all-reduce buckets early)."""
+        B, H, W = ws.B, ws.H, ws.W
+        dev = dlogits.device
+        dlogits = dlogits.contiguous().float()
+        st = _lib.stream_ptr()
+        by = {L.name: L for L in self.layers}
+        sc = ws.bwd_scratch(dev)
+        td, es = self.tdtype, self.esize
+        e = lambda *s: torch.empty(*s, dtype=td, device=dev)
+        ready = on_ready or (lambda keys: None)
+
+        def bn_bwd(L, dA, ldA, n, ipg):
+            hk, wk = ws.dims[L.level - 1]
+            dz = e(n, hk, wk, L.cout)
+            call('bdn_bn_bwd', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
+                 ptr(sc['bnb']), ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
+            return dz
+
+        def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
+            hk, wk = ws.dims[L.level - 1]
+            call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
+                 ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, st)
+            grads[f'{L.conv}.bias'].zero_()          # feeds a BatchNorm: gradient is identically zero
+            ready([f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias'])
+
+        def dgrad(L, dz, n, ipg):
+            hk, wk = ws.dims[L.level - 1]
+            _, wd = self._weights(L, P, True)
+            out = e(n, hk, wk, L.cin)
+            call('bdn_conv3x3', self.dt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
+                 ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
+            return out
+
+        # ---- classifier
+        L4b = by['d4b']
+        dA = e(B, H, W, L4b.cout)
+        call('bdn_outc_bwd', self.dt, ptr(dlogits), ptr(ws.z['d4b']), ptr(ws.bn['d4b']), ptr(P['outc.conv.weight']),
+             ptr(dA), ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), B, H, W, L4b.cout, self.n_classes, st)
+        ready(['outc.conv.weight', 'outc.conv.bias'])
+        # ---- decoder
+        dA_ptr, ldA = ptr(dA), L4b.cout
+        keep = [dA]
+        dcat = {}
+        dF5 = None
+        for j in range(4, 0, -1):
+            k = 5 - j
+            hk, wk = ws.dims[k - 1]
+            hs, wsrc = ws.dims[k]
+            La, Lb = by[f'd{j}a'], by[f'd{j}b']
+            ck = ENC_CH[k - 1]
+            cprev = La.cin - ck
+            dzb = bn_bwd(Lb, dA_ptr, ldA, B, B)
+            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
+            dAa = dgrad(Lb, dzb, B, B)
+            dza = bn_bwd(La, ptr(dAa), La.cout, B, B)
+            wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
+            dc = dgrad(La, dza, B, B)                       # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
+            dcat[k] = dc
+            dprev = e(B, hs, wsrc, cprev)
+            call('bdn_upsample2x_bwd', self.dt, dc.data_ptr() + ck * es, La.cin, ptr(dprev), B, hs, wsrc, hk, wk, cprev, st)
+            keep += [dzb, dAa, dza, dprev]
+            if j > 1:
+                dA_ptr, ldA = ptr(dprev), cprev
+            else:
+                dF5 = dprev
+        # ---- encoder (both dates at once)
+        dP = None
+        for k in range(5, 0, -1):
+            hk, wk = ws.dims[k - 1]
+            La, Lb = by[f'e{k}a'], by[f'e{k}b']
+            ck = ENC_CH[k - 1]
+            if k == 5:
+                dF_ptr, ldF = ptr(dF5), ck
+            else:
+                dF_ptr, ldF = ptr(dcat[k]), dcat[k].shape[3]
+            dAb = e(2 * B, hk, wk, ck)
+            call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
+                 ptr(dP), ptr(dAb), B, hk, wk, ck, st)
+            dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B)
+            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
+            dAa = dgrad(Lb, dzb, 2 * B, B)
+            dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B)
+            src = ws.x0 if k == 1 else ws.pool[k]
+            wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
+            keep += [dAb, dzb, dAa, dza, dP]
+            dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
+        return grads

@@ -1,0 +1,78 @@
+"""BiDateNet: drop-in for the reference's models/bidate_model.py:7-40.
+
+Same constructor, same ``forward(x_d1, x_d2)`` (two [B,C,H,W] float32 tensors ->
+[B,n_classes,H,W] float32 logits that take part in autograd), same sub-module
+tree / ``state_dict()`` schema, ``.train()/.eval()`` switch BatchNorm mode.  The
+whole forward + backward runs on the gfx950 HIP library; there is no CPU path.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .unet_parts import down, outconv, up, inconv
+from ..engine import BiDateEngine
+
+
+class _BiDateFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward enqueues the fused HIP schedule, backward the
+    hand-written backward schedule (no autograd tape through individual ops)."""
+
+    @staticmethod
+    def forward(ctx, module, x_d1, x_d2, *params):
+        eng = module.engine()
+        P = dict(module.state_dict(keep_vars=True))
+        training = module.training
+        logits, ws = eng.forward(x_d1.detach(), x_d2.detach(), {k: v.detach() for k, v in P.items()}, training)
+        ctx.module, ctx.ws, ctx.training = module, ws, training
+        ctx.n_params = len(params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module = ctx.module
+        if not ctx.training:
+            raise RuntimeError('fabric_amd: backward through an eval-mode forward is not supported '
+                               '(BatchNorm used running statistics); call model.train() first')
+        eng = module.engine()
+        named = list(module.named_parameters())
+        P = {k: v.detach() for k, v in module.state_dict(keep_vars=True).items()}
+        grads = {k: torch.empty_like(p, dtype=torch.float32) for k, p in named}
+        eng.backward(ctx.ws, dlogits, P, grads)
+        return (None, None, None) + tuple(grads[k] for k, _ in named)
+
+
+class BiDateNet(nn.Module):
+    def __init__(self, n_channels, n_classes, precision=None):
+        super(BiDateNet, self).__init__()
+        self.inc = inconv(n_channels, 64)
+        self.down1 = down(64, 128)
+        self.down2 = down(128, 256)
+        self.down3 = down(256, 512)
+        self.down4 = down(512, 512)
+
+        self.up1 = up(1024, 256)
+        self.up2 = up(512, 128)
+        self.up3 = up(256, 64)
+        self.up4 = up(128, 64)
+        self.outc = outconv(64, n_classes)
+
+        self.n_channels, self.n_classes = n_channels, n_classes
+        # 'bf16' = throughput setting, 'fp32' = 1e-3-parity setting
+        self.precision = precision or os.environ.get('BIDATE_PRECISION', 'bf16')
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None or self._engine.precision != self.precision:
+            self._engine = BiDateEngine(self.n_channels, self.n_classes, self.precision)
+        return self._engine
+
+    def forward(self, x_d1, x_d2):
+        params = [p for _, p in self.named_parameters()]
+        return _BiDateFunction.apply(self, x_d1, x_d2, *params)
+
+    # the engine and its workspaces are derived state: keep them out of pickles / deepcopies
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d['_engine'] = None
+        return d

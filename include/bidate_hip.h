@@ -1,0 +1,146 @@
+/*
+ * bidate_hip.h -- C ABI of libbidate_hip.so: hand-written gfx950 (MI355X / CDNA4)
+ * kernels for the bi-date Siamese U-Net training path of granularai/fabric.
+ *
+ * The reference has no FFI: its hot path is a set of ATen call sites reached from
+ * Python.  Each entry point below names the reference call site(s)
+ * (file:line relative to the reference root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching
+ *     allocator); the library never allocates, frees or synchronises;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns;
+ *   - return value: 0 = ok, negative = error (BDN_E_*); bdn_last_error() gives a
+ *     thread-local message.  No C++ exception crosses the boundary;
+ *   - activations are NHWC; `dtype` selects the element type of activations and
+ *     packed weights: BDN_F32 (f32 storage, v_mfma_f32_32x32x2_f32: the
+ *     "fp32-equivalent" parity setting) or BDN_BF16 (bf16 storage,
+ *     v_mfma_f32_32x32x16_bf16, fp32 accumulate: the throughput setting);
+ *   - BatchNorm statistics are kept per *group* (= date): images
+ *     [g*imgs_per_group, (g+1)*imgs_per_group) of a batch form group g
+ *     (models/bidate_model.py:23-33 runs the shared BN modules once per date).
+ */
+#ifndef BIDATE_HIP_H
+#define BIDATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { BDN_F32 = 0, BDN_BF16 = 1 };
+enum { BDN_OK = 0, BDN_E_ARG = -1, BDN_E_SHAPE = -2, BDN_E_HIP = -3 };
+enum { BDN_IN_PLAIN = 0, BDN_IN_BNRELU = 1 };
+
+const char* bdn_last_error(void);
+int bdn_version(void);
+
+/* ---- layout converters (boundary of BiDateNet.forward, models/bidate_model.py:22) ---- */
+/* x_d1, x_d2: [B,C,H,W] f32 NCHW  ->  out: [2B,H,W,Cpad] (date-1 images first), channels >= C zeroed. */
+int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,
+                   int B, int C, int H, int W, int Cpad, void* stream);
+/* OIHW f32 [Cout,Cin,3,3] -> forward GEMM image wf [Cout][9][Cin_pad] and the data-gradient image
+ * wd [Cin_pad][9][Cout] (taps rotated by 180 degrees); either output may be NULL. */
+int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
+                     int Cout, int Cin, int Cin_pad, void* stream);
+
+/* ---- 3x3 convolution, stride 1, zero padding 1: nn.Conv2d(ci,co,3,padding=1), models/unet_parts.py:13,16 ----
+ * Implicit GEMM on MFMA.  The A operand is gathered from in0 (channels [0,C0)) and optionally in1
+ * (channels [C0,C0+C1), the never-materialised torch.cat of models/unet_parts.py:78).
+ * in_mode BDN_IN_BNRELU applies relu(z*scale+shift) (BatchNorm2d+ReLU of the producing layer,
+ * models/unet_parts.py:14-15,17-18) while loading in0; in_bn is that layer's [G][4][C0] f32 table
+ * written by bdn_bn_finalize / bdn_bn_eval.
+ * w: packed [Cout][9][C0+C1]; bias: [Cout] f32 or NULL.
+ * out: [N,H,W,Cout].  stats_partial: NULL or [bdn_conv3x3_num_mtiles][2][Cout] f32 receiving
+ * per-tile sum / sum-of-squares of the (bias-included, f32) outputs for the BatchNorm that follows.
+ * The same entry point computes the data gradient when given wd and dz. */
+int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
+                int in_mode, const float* in_bn, int imgs_per_group,
+                const void* w, const float* bias, void* out, float* stats_partial,
+                int N, int H, int W, int Cout, void* stream);
+int bdn_conv3x3_num_mtiles(int N, int H, int W, int imgs_per_group);
+
+/* ---- weight gradient of the same convolution (autograd of models/unet_parts.py:13,16) ----
+ * dz: [N,H,W,Cout]; inputs as in bdn_conv3x3.  partial: workspace of bdn_wgrad_workspace_bytes().
+ * dw_oihw: f32 [Cout,Cin_real,3,3] (overwritten; channels >= Cin_real of a padded input are dropped). */
+size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group);
+int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
+                      const void* in0, int C0, const void* in1, int C1,
+                      int in_mode, const float* in_bn, int imgs_per_group,
+                      float* partial, float* dw_oihw, int Cin_real,
+                      int N, int H, int W, void* stream);
+
+/* ---- BatchNorm2d training statistics: nn.BatchNorm2d, models/unet_parts.py:14,17 ----
+ * Reduces the conv's per-tile partials and produces, per group g and channel c,
+ * bn[g][0..3][c] = {mean, invstd, scale = gamma*invstd, shift = beta - mean*scale}  (layout [G][4][C]),
+ * then updates running_mean/var (momentum 0.1, unbiased variance) once per group in order g=0,1,..
+ * and adds G to num_batches_tracked -- the reference calls the module once per date. */
+int bdn_bn_finalize(const float* stats_partial, int n_mtiles, int G, int C, int count_per_group,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* bn, void* stream);
+/* Eval mode: bn[0][..] from the running buffers (mean=rm, invstd=rsqrt(rv+eps)), replicated for G groups. */
+int bdn_bn_eval(const float* gamma, const float* beta, const float* running_mean,
+                const float* running_var, float eps, int G, int C, float* bn, void* stream);
+
+/* ---- BatchNorm2d + ReLU backward (autograd of models/unet_parts.py:14-15,17-18) ----
+ * g = dA * [z*scale+shift > 0]; sums[g][0][c] = sum g, sums[g][1][c] = sum g*xhat (layout [G][2][C]);
+ * dgamma/dbeta (accumulated over groups, overwritten) ; dz = scale*(g - s0/M - xhat*s1/M).
+ * dA: [N,H,W,ldA] channel slice starting at dA pointer (ldA = channel stride of the dA tensor).
+ * ws: workspace of bdn_bn_bwd_workspace_bytes(). */
+size_t bdn_bn_bwd_workspace_bytes(int N, int H, int W, int C);
+int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* bn,
+               int imgs_per_group, int N, int H, int W, int C,
+               float* ws, float* sums, float* dgamma, float* dbeta, void* dz, void* stream);
+
+/* ---- nn.MaxPool2d(2) on relu(bn(z)): models/unet_parts.py:40 (floor mode) ---- */
+int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_group,
+                    void* out, int N, int H, int W, int C, void* stream);
+
+/* ---- date fusion torch.relu(x_d2 * x_d1): models/bidate_model.py:35-38 ----
+ * z: [2B,H,W,C] raw conv outputs of both dates, bn: [2][4][C]; f: [B,H,W,C]. */
+int bdn_fuse_product(int dtype, const void* z, const float* bn, void* f,
+                     int B, int H, int W, int C, void* stream);
+
+/* ---- nn.Upsample(scale_factor=2, bilinear, align_corners=True) + F.pad: models/unet_parts.py:56-58,68-72 ----
+ * src: [B,h,w,C] (plain, or raw z with bn when in_mode = BDN_IN_BNRELU); out: [B,H,W,C] with the
+ * 2h x 2w map placed at offset ((H-2h)/2, (W-2w)/2) and zeros elsewhere. */
+int bdn_upsample2x(int dtype, const void* src, int in_mode, const float* bn,
+                   void* out, int B, int h, int w, int H, int W, int C, void* stream);
+/* Transpose of the above: dU: [B,H,W,ldU] channel slice -> dsrc: [B,h,w,C]. */
+int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
+                       int B, int h, int w, int H, int W, int C, void* stream);
+
+/* ---- backward of the date fusion and of MaxPool2d into the encoder outputs ----
+ * dF: [B,H,W,ldF] slice; z: [2B,H,W,C], bn [2][4][C]; dP: NULL or [2B,H/2,W/2,C] gradient of the
+ * pooled map; dA: [2B,H,W,C] = gradient wrt relu(bn(z)) of each date:
+ * dA_d1 = dF * a_d2 + unpool(dP_d1), dA_d2 = dF * a_d1 + unpool(dP_d2)  (first maximum wins ties). */
+int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const float* bn,
+                     const void* dP, void* dA, int B, int H, int W, int C, void* stream);
+
+/* ---- outconv: nn.Conv2d(64, n_classes, 1), models/unet_parts.py:86 ----
+ * z: [B,H,W,C] raw output of up4's second conv, bn: [1][4][C]; w: [ncls][C] f32, b: [ncls];
+ * logits: [B,ncls,H,W] f32 NCHW (the reference's output layout). */
+int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, const float* b,
+                 float* logits, int B, int H, int W, int C, int ncls, void* stream);
+/* dlogits: [B,ncls,H,W] f32 -> dA [B,H,W,C] (wrt relu(bn(z))), dw [ncls][C], db [ncls] (overwritten). */
+int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
+                 void* dA, float* dw, float* db, int B, int H, int W, int C, int ncls, void* stream);
+
+/* ---- TverskyLoss.forward, utils/metrics.py:130-171, for [B,H,W] labels (dims == (0,2)) ----
+ * labels: uint8 [B,H,W].  ws: f32 workspace of 3*ncls*W + 8 floats.
+ * loss: f32 scalar.  counts: NULL or int32[4] = {TP, FP, FN, correct} of argmax(logits) vs labels
+ * (class 1 positive; train.py:96-106).  dlogits: NULL or [B,ncls,H,W] = d loss / d logits. */
+int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
+                float* ws, float* loss, int32_t* counts, float* dlogits,
+                int B, int ncls, int H, int W, void* stream);
+
+/* ---- optim.SGD(lr) step, train.py:55,95: p -= lr * grad_scale * g over a flat f32 buffer ---- */
+int bdn_sgd_step(float* params, const float* grads, float lr, float grad_scale, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIDATE_HIP_H */

@@ -1,0 +1,414 @@
+"""-m gpu parity tests, one per C-ABI entry point, against the CPU oracle (oracle/bidate_oracle.py).
+
+Tolerances: 'fp32' = f32 storage + f32 MFMA: 2e-5 of the result's max magnitude (summation-order
+noise only).  'bf16': inputs are pre-rounded to bf16 so the only differences are the bf16 rounding
+of the *output* (2^-9 relative) and fp32 summation order: 1e-2 of max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fabric_amd import _lib
+from fabric_amd._lib import IN_BNRELU, IN_PLAIN
+from oracle import bidate_oracle as O
+from tests.gpu_util import (DT, assert_close, bn_table, bnrelu_ref, dev, from_nhwc, pack_w, rnd, st, to_nhwc)
+
+pytestmark = pytest.mark.gpu
+TOL = {'fp32': 2e-5, 'bf16': 1e-2}
+PRECS = ['fp32', 'bf16']
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+# ------------------------------------------------------------------ conv3x3 forward (+ stats) and BN finalize
+CONV_CASES = [
+    # N, H, W, C0real, C0, C1, Cout, bnrelu, ipg
+    (4, 32, 32, 13, 16, 0, 64, False, 2),      # first layer: 13 bands padded to 16, two date groups
+    (2, 16, 16, 64, 64, 0, 128, True, 1),      # BN+ReLU applied on load, one image per group
+    (2, 24, 20, 64, 64, 64, 64, False, 2),     # two-source K loop (skip | upsampled), ragged tiles
+    (4, 8, 8, 128, 128, 0, 128, True, 2),      # 8x8 maps: two images per tile
+    (2, 5, 5, 64, 64, 0, 64, False, 2),        # odd tiny map (90-pixel patches end at 5x5)
+    (1, 11, 45, 64, 64, 0, 192, True, 1),      # odd sizes, Cout not a multiple of 128
+    (3, 17, 16, 128, 128, 128, 256, False, 3), # three images, two sources
+]
+
+
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv3x3_forward_stats_finalize(prec, case):
+    N, H, W, c0r, C0, C1, Cout, bnrelu, ipg = case
+    dt, td = DT[prec]
+    G = N // ipg
+    x0 = rnd(prec, _rand((N, C0, H, W), 1))
+    x0[:, c0r:] = 0
+    x1 = rnd(prec, _rand((N, C1, H, W), 2)) if C1 else None
+    w = _rand((Cout, c0r + C1, 3, 3), 3, (2.0 / (9 * (c0r + C1))) ** 0.5)
+    b = _rand((Cout,), 4, 0.1)
+    bn_in = bn_table(G, C0, 5) if bnrelu else None
+    # ---- oracle
+    a0 = bnrelu_ref(prec, x0, bn_in, ipg) if bnrelu else x0
+    a = torch.cat([a0[:, :c0r], x1], 1) if C1 else a0[:, :c0r]
+    z_ref = O.conv3x3(a, rnd(prec, w), b)
+    # ---- device
+    wp = torch.zeros(Cout, C0 + C1, 3, 3)
+    wp[:, :c0r] = w[:, :c0r]
+    if C1:
+        wp[:, C0:] = w[:, c0r:]
+    wf, _ = pack_w(prec, wp, C0 + C1)
+    d0, d1 = to_nhwc(prec, x0), (to_nhwc(prec, x1) if C1 else None)
+    out = torch.empty(N, H, W, Cout, dtype=td, device='cuda')
+    nt = _lib.load().bdn_conv3x3_num_mtiles(N, H, W, ipg)
+    stats = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    dbn = dev(bn_in) if bnrelu else None
+    db = dev(b)
+    _lib.call('bdn_conv3x3', dt, d0.data_ptr(), C0, d1.data_ptr() if C1 else None, C1,
+              IN_BNRELU if bnrelu else IN_PLAIN, dbn.data_ptr() if bnrelu else None, ipg,
+              wf.data_ptr(), db.data_ptr(), out.data_ptr(), stats.data_ptr(), N, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert_close('conv out', from_nhwc(out), z_ref, TOL[prec])
+    # ---- stats partials -> BatchNorm table and running buffers
+    gamma, beta = _rand((Cout,), 6).abs() + 0.5, _rand((Cout,), 7, 0.3)
+    rm0, rv0 = _rand((Cout,), 8, 0.2), _rand((Cout,), 9).abs() + 0.5
+    drm, drv = dev(rm0), dev(rv0)
+    nbt = torch.zeros(1, dtype=torch.int64, device='cuda')
+    bn = torch.empty(G, 4, Cout, device='cuda')
+    dg, dbeta = dev(gamma), dev(beta)
+    _lib.call('bdn_bn_finalize', stats.data_ptr(), nt, G, Cout, ipg * H * W, dg.data_ptr(), dbeta.data_ptr(),
+              1e-5, 0.1, drm.data_ptr(), drv.data_ptr(), nbt.data_ptr(), bn.data_ptr(), st())
+    torch.cuda.synchronize()
+    bn = bn.cpu()
+    rm, rv = rm0.clone(), rv0.clone()
+    tol_s = 5e-5 if prec == 'fp32' else 2e-3        # bf16: statistics come from the f32 accumulators, z_ref is exact
+    for g in range(G):
+        zg = z_ref[g * ipg:(g + 1) * ipg].double()
+        mean = zg.mean((0, 2, 3))
+        var = zg.var((0, 2, 3), unbiased=False)
+        n = ipg * H * W
+        inv = 1 / torch.sqrt(var + 1e-5)
+        assert_close(f'mean g{g}', bn[g, 0], mean.float(), tol_s, 1e-5)
+        assert_close(f'invstd g{g}', bn[g, 1], inv.float(), tol_s)
+        assert_close(f'scale g{g}', bn[g, 2], (gamma * inv).float(), tol_s)
+        assert_close(f'shift g{g}', bn[g, 3], (beta - mean * gamma * inv).float(), tol_s, 1e-5)
+        rm = 0.9 * rm + 0.1 * mean.float()
+        rv = 0.9 * rv + 0.1 * (var * n / max(n - 1, 1)).float()
+    assert_close('running_mean', drm.cpu(), rm, tol_s, 1e-6)
+    assert_close('running_var', drv.cpu(), rv, tol_s, 1e-6)
+    assert int(nbt.item()) == G
+
+
+# ------------------------------------------------------------------ data gradient through the same kernel
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 128, 1), (2, 8, 8, 256, 128, 2), (1, 22, 45, 192, 64, 1)])
+def test_conv3x3_dgrad(prec, case):
+    N, H, W, Cin, Cout, ipg = case
+    dt, td = DT[prec]
+    dz = rnd(prec, _rand((N, Cout, H, W), 11))
+    w = rnd(prec, _rand((Cout, Cin, 3, 3), 12, 0.05))
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dz, padding=1)
+    _, wd = pack_w(prec, w, Cin)
+    ddz = to_nhwc(prec, dz)
+    out = torch.empty(N, H, W, Cin, dtype=td, device='cuda')
+    _lib.call('bdn_conv3x3', dt, ddz.data_ptr(), Cout, None, 0, IN_PLAIN, None, ipg, wd.data_ptr(), None,
+              out.data_ptr(), None, N, H, W, Cin, st())
+    torch.cuda.synchronize()
+    assert_close('dgrad', from_nhwc(out), ref, TOL[prec])
+
+
+# ------------------------------------------------------------------ weight gradient
+WG_CASES = [
+    # N, H, W, C0real, C0, C1, Cout, bnrelu, ipg
+    (4, 32, 32, 13, 16, 0, 64, False, 2),
+    (2, 16, 16, 64, 64, 0, 128, True, 1),
+    (2, 24, 20, 64, 64, 64, 64, False, 2),
+    (4, 8, 8, 128, 128, 0, 64, True, 2),
+    (2, 5, 11, 64, 64, 0, 64, False, 1),
+    (8, 16, 16, 64, 64, 0, 64, True, 4),
+]
+
+
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', WG_CASES)
+def test_conv3x3_wgrad(prec, case):
+    N, H, W, c0r, C0, C1, Cout, bnrelu, ipg = case
+    dt, td = DT[prec]
+    G = N // ipg
+    x0 = rnd(prec, _rand((N, C0, H, W), 21))
+    x0[:, c0r:] = 0
+    x1 = rnd(prec, _rand((N, C1, H, W), 22)) if C1 else None
+    dz = rnd(prec, _rand((N, Cout, H, W), 23))
+    bn_in = bn_table(G, C0, 24) if bnrelu else None
+    a0 = bnrelu_ref(prec, x0, bn_in, ipg) if bnrelu else x0
+    a = torch.cat([a0[:, :c0r], x1], 1) if C1 else a0[:, :c0r]
+    ref = torch.nn.grad.conv2d_weight(a.double(), (Cout, c0r + C1, 3, 3), dz.double(), padding=1).float()
+    d0, d1, ddz = to_nhwc(prec, x0), (to_nhwc(prec, x1) if C1 else None), to_nhwc(prec, dz)
+    nbytes = _lib.load().bdn_wgrad_workspace_bytes(N, H, W, Cout, C0 + C1, ipg)
+    part = torch.empty(nbytes // 4, device='cuda')
+    cin_real = c0r + C1 if not C1 else C0 + C1
+    dw = torch.full((Cout, cin_real, 3, 3), float('nan'), device='cuda')
+    dbn = dev(bn_in) if bnrelu else None
+    _lib.call('bdn_conv3x3_wgrad', dt, ddz.data_ptr(), Cout, d0.data_ptr(), C0, d1.data_ptr() if C1 else None, C1,
+              IN_BNRELU if bnrelu else IN_PLAIN, dbn.data_ptr() if bnrelu else None, ipg,
+              part.data_ptr(), dw.data_ptr(), cin_real, N, H, W, st())
+    torch.cuda.synchronize()
+    got = dw.cpu()
+    if C1:   # the padded first source keeps its zero channels in this layout
+        got = torch.cat([got[:, :c0r], got[:, C0:]], 1)
+    assert_close('wgrad', got, ref, 2e-5 if prec == 'fp32' else 2e-5)   # inputs pre-rounded, f32 accumulate & output
+
+
+# ------------------------------------------------------------------ BatchNorm + ReLU backward
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', [(4, 16, 16, 64, 2, 0), (2, 9, 7, 128, 1, 64), (6, 8, 8, 512, 3, 0)])
+def test_bn_bwd(prec, case):
+    N, H, W, C, ipg, extra = case
+    dt, td = DT[prec]
+    G = N // ipg
+    ld = C + extra
+    z = rnd(prec, _rand((N, C, H, W), 31))
+    dA_full = rnd(prec, _rand((N, ld, H, W), 32))
+    gamma = _rand((C,), 33).abs() + 0.5
+    gamma[::7] *= -1
+    beta = _rand((C,), 34, 0.3)
+    # table from the true batch statistics of z
+    bn = torch.empty(G, 4, C)
+    zs = z.clone().double().requires_grad_(True)
+    ys = []
+    for g in range(G):
+        zg = zs[g * ipg:(g + 1) * ipg]
+        mean, var = zg.mean((0, 2, 3)), zg.var((0, 2, 3), unbiased=False)
+        inv = 1 / torch.sqrt(var + 1e-5)
+        bn[g, 0], bn[g, 1] = mean.detach().float(), inv.detach().float()
+        bn[g, 2] = (gamma * inv.detach()).float()
+        bn[g, 3] = (beta - mean.detach() * gamma * inv.detach()).float()
+        y = (zg - mean[None, :, None, None]) * (inv * gamma.double())[None, :, None, None] + beta.double()[None, :, None, None]
+        ys.append(torch.relu(y))
+    gd = dA_full[:, extra:extra + C].double()
+    gs = gamma.double().clone().requires_grad_(True)     # for dgamma use an explicit formula below
+    torch.cat(ys).backward(gd)
+    dz_ref = zs.grad.float()
+    # dgamma / dbeta by the explicit formula
+    a = torch.cat(ys).detach()
+    gm = gd * (a > 0)
+    dbeta_ref = gm.sum((0, 2, 3)).float()
+    xhat = torch.cat([(z[g * ipg:(g + 1) * ipg].double() - bn[g, 0].double()[None, :, None, None]) * bn[g, 1].double()[None, :, None, None] for g in range(G)])
+    dgamma_ref = (gm * xhat).sum((0, 2, 3)).float()
+    # ---- device
+    dz_d = torch.empty(N, H, W, C, dtype=td, device='cuda')
+    dA_d = to_nhwc(prec, dA_full)
+    z_d = to_nhwc(prec, z)
+    wsb = torch.empty(_lib.load().bdn_bn_bwd_workspace_bytes(N, H, W, C) // 4, device='cuda')
+    sums = torch.empty(G, 2, C, device='cuda')
+    dgam, dbet = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    bn_d = dev(bn)
+    es = 2 if prec == 'bf16' else 4
+    _lib.call('bdn_bn_bwd', dt, dA_d.data_ptr() + extra * es, ld, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, C,
+              wsb.data_ptr(), sums.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), dz_d.data_ptr(), st())
+    torch.cuda.synchronize()
+    assert_close('dbeta', dbet.cpu(), dbeta_ref, 1e-4)
+    assert_close('dgamma', dgam.cpu(), dgamma_ref, 1e-4)
+    assert_close('dz', from_nhwc(dz_d), dz_ref, 1e-4 if prec == 'fp32' else 1e-2)
+
+
+# ------------------------------------------------------------------ pool / product / upsample and their backward
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('shape', [(4, 16, 16, 64, 2), (2, 45, 22, 64, 1), (2, 11, 11, 128, 1)])
+def test_bnrelu_pool(prec, shape):
+    N, H, W, C, ipg = shape
+    dt, td = DT[prec]
+    z = rnd(prec, _rand((N, C, H, W), 41))
+    bn = bn_table(N // ipg, C, 42)
+    ref = O.maxpool2(bnrelu_ref(prec, z, bn, ipg))
+    out = torch.empty(N, H // 2, W // 2, C, dtype=td, device='cuda')
+    z_d, bn_d = to_nhwc(prec, z), dev(bn)
+    _lib.call('bdn_bnrelu_pool', dt, z_d.data_ptr(), bn_d.data_ptr(), ipg, out.data_ptr(), N, H, W, C, st())
+    torch.cuda.synchronize()
+    assert_close('pool', from_nhwc(out), ref, 1e-6 if prec == 'fp32' else 8e-3)
+
+
+@pytest.mark.parametrize('prec', PRECS)
+def test_fuse_product(prec):
+    B, H, W, C = 3, 10, 12, 64
+    dt, td = DT[prec]
+    z = rnd(prec, _rand((2 * B, C, H, W), 43))
+    bn = bn_table(2, C, 44)
+    a = bnrelu_ref(prec, z, bn, B)
+    ref = torch.relu(a[B:] * a[:B])                      # models/bidate_model.py:35
+    out = torch.empty(B, H, W, C, dtype=td, device='cuda')
+    z_d, bn_d = to_nhwc(prec, z), dev(bn)
+    _lib.call('bdn_fuse_product', dt, z_d.data_ptr(), bn_d.data_ptr(), out.data_ptr(), B, H, W, C, st())
+    torch.cuda.synchronize()
+    assert_close('product', from_nhwc(out), ref, 1e-6 if prec == 'fp32' else 8e-3)
+
+
+UP_CASES = [(2, 8, 8, 16, 16, 64), (2, 5, 5, 11, 11, 64), (1, 22, 22, 45, 45, 32), (2, 1, 1, 2, 3, 16), (1, 3, 7, 6, 14, 64)]
+
+
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', UP_CASES)
+@pytest.mark.parametrize('bnrelu', [False, True])
+def test_upsample2x_and_backward(prec, case, bnrelu):
+    B, h, w, H, W, C = case
+    dt, td = DT[prec]
+    src = rnd(prec, _rand((B, C, h, w), 45))
+    bn = bn_table(1, C, 46)
+    a = bnrelu_ref(prec, src, bn, B) if bnrelu else src
+    skip = torch.zeros(B, 1, H, W)
+    a_req = a.clone().double().requires_grad_(True)
+    ref = O.pad_to(O.upsample2x_align(a_req), skip)
+    # cross-check the oracle's bilinear against torch's own
+    tref = O.pad_to(F.interpolate(a.double(), scale_factor=2, mode='bilinear', align_corners=True), skip)
+    assert (ref.detach() - tref).abs().max() < 1e-6
+    out = torch.empty(B, H, W, C, dtype=td, device='cuda')
+    s_d, bn_d = to_nhwc(prec, src), dev(bn)
+    _lib.call('bdn_upsample2x', dt, s_d.data_ptr(), IN_BNRELU if bnrelu else IN_PLAIN, bn_d.data_ptr(),
+              out.data_ptr(), B, h, w, H, W, C, st())
+    torch.cuda.synchronize()
+    assert_close('upsample', from_nhwc(out), ref.detach().float(), 1e-5 if prec == 'fp32' else 8e-3)
+    if bnrelu:
+        return
+    # backward: dU lives in a wider tensor (channel slice), like the decoder's [dF | dU] gradient
+    extra = 16
+    dU = rnd(prec, _rand((B, C + extra, H, W), 47))
+    ref.backward(dU[:, extra:].double())
+    dsrc = torch.empty(B, h, w, C, dtype=td, device='cuda')
+    dU_d = to_nhwc(prec, dU)
+    es = 2 if prec == 'bf16' else 4
+    _lib.call('bdn_upsample2x_bwd', dt, dU_d.data_ptr() + extra * es, C + extra, dsrc.data_ptr(), B, h, w, H, W, C, st())
+    torch.cuda.synchronize()
+    assert_close('upsample bwd', from_nhwc(dsrc), a_req.grad.float(), 1e-5 if prec == 'fp32' else 8e-3)
+
+
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, True), (2, 11, 45, 64, True), (3, 8, 8, 128, False), (1, 5, 5, 64, True)])
+def test_enc_skip_bwd(prec, case):
+    B, H, W, C, pooled = case
+    dt, td = DT[prec]
+    z = rnd(prec, _rand((2 * B, C, H, W), 51))
+    bn = bn_table(2, C, 52)
+    extra = 32
+    dF = rnd(prec, _rand((B, C + extra, H, W), 53))
+    dP = rnd(prec, _rand((2 * B, C, H // 2, W // 2), 54)) if pooled else None
+    a = bnrelu_ref(prec, z, bn, B).double().requires_grad_(True)
+    loss = (torch.relu(a[B:] * a[:B]) * dF[:, :C].double()).sum()
+    if pooled:
+        loss = loss + (O.maxpool2(a) * dP.double()).sum()
+    loss.backward()
+    ref = a.grad.float()
+    out = torch.empty(2 * B, H, W, C, dtype=td, device='cuda')
+    dF_d, z_d, bn_d = to_nhwc(prec, dF), to_nhwc(prec, z), dev(bn)
+    dP_d = to_nhwc(prec, dP) if pooled else None
+    _lib.call('bdn_enc_skip_bwd', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
+              dP_d.data_ptr() if pooled else None, out.data_ptr(), B, H, W, C, st())
+    torch.cuda.synchronize()
+    # Where a == 0 the reference's relu(a2*a1) has zero slope while the kernel returns dF*a_other; both are
+    # multiplied by the producer's own ReLU mask [a > 0] in the very next step (bn_bwd), so compare there.
+    live = (a.detach() > 0).float()
+    assert_close('enc_skip_bwd', from_nhwc(out) * live, ref * live, 1e-6 if prec == 'fp32' else 8e-3)
+
+
+# ------------------------------------------------------------------ classifier
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64, 2), (1, 9, 13, 64, 3)])
+def test_outc_fwd_bwd(prec, shape):
+    B, H, W, C, ncls = shape
+    dt, td = DT[prec]
+    z = rnd(prec, _rand((B, C, H, W), 61))
+    bn = bn_table(1, C, 62)
+    w, b = _rand((ncls, C, 1, 1), 63, 0.2), _rand((ncls,), 64, 0.1)
+    a = bnrelu_ref(prec, z, bn, B).double().requires_grad_(True)
+    wd_, bd_ = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = O.conv1x1(a, wd_, bd_)
+    logits = torch.empty(B, ncls, H, W, device='cuda')
+    z_d, bn_d, w_d, b_d = to_nhwc(prec, z), dev(bn), dev(w), dev(b)
+    _lib.call('bdn_outc_fwd', dt, z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), b_d.data_ptr(), logits.data_ptr(), B, H, W, C, ncls, st())
+    torch.cuda.synchronize()
+    assert_close('logits', logits.cpu(), ref.detach().float(), 1e-5)
+    dl = _rand((B, ncls, H, W), 65)
+    ref.backward(dl.double())
+    dA = torch.empty(B, H, W, C, dtype=td, device='cuda')
+    dw, db = torch.empty(ncls, C, device='cuda'), torch.empty(ncls, device='cuda')
+    dl_d = dev(dl)
+    _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), dA.data_ptr(),
+              dw.data_ptr(), db.data_ptr(), B, H, W, C, ncls, st())
+    torch.cuda.synchronize()
+    assert_close('dA', from_nhwc(dA), a.grad.float(), 1e-5 if prec == 'fp32' else 8e-3)
+    assert_close('dw', dw.cpu(), wd_.grad.float().reshape(ncls, C), 1e-4)
+    assert_close('db', db.cpu(), bd_.grad.float(), 1e-4)
+
+
+# ------------------------------------------------------------------ Tversky loss
+@pytest.mark.parametrize('shape', [(3, 2, 24, 20), (2, 3, 16, 300), (64, 2, 128, 128)])
+def test_tversky(shape):
+    B, ncls, H, W = shape
+    logits = _rand((B, ncls, H, W), 71)
+    labels = torch.from_numpy((np.random.default_rng(72).uniform(0, 1, (B, H, W)) < 0.2).astype(np.uint8))
+    lg = logits.double().requires_grad_(True)
+    ref = O.tversky_loss(lg, labels.long(), 0.1, 0.9)
+    ref.backward()
+    ws = torch.empty(3 * ncls * W + 8, device='cuda')
+    loss = torch.empty(1, device='cuda')
+    counts = torch.empty(4, dtype=torch.int32, device='cuda')
+    dl = torch.empty(B, ncls, H, W, device='cuda')
+    lg_d, lb_d = dev(logits), labels.cuda()
+    _lib.call('bdn_tversky', lg_d.data_ptr(), lb_d.data_ptr(), 0.1, 0.9, 1e-7, ws.data_ptr(), loss.data_ptr(),
+              counts.data_ptr(), dl.data_ptr(), B, ncls, H, W, st())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 2e-6
+    assert_close('dlogits', dl.cpu(), lg.grad.float(), 2e-4)
+    preds = logits.argmax(1)
+    lab = labels.long()
+    exp = [int(((preds == 1) & (lab == 1)).sum()), int(((preds == 1) & (lab != 1)).sum()),
+           int(((preds != 1) & (lab == 1)).sum()), int((preds == lab).sum())]
+    assert counts.cpu().tolist() == exp
+
+
+def test_tversky_golden(golden_dir):
+    """utils/metrics.py:130-171 value + gradient captured from the reference itself (G5)."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'g5_losses.npz'))
+    logits, labels = torch.from_numpy(g['logits']), torch.from_numpy(g['labels'])
+    B, ncls, H, W = logits.shape
+    ws = torch.empty(3 * ncls * W + 8, device='cuda')
+    loss = torch.empty(1, device='cuda')
+    dl = torch.empty(B, ncls, H, W, device='cuda')
+    lg_d, lb_d = dev(logits), labels.cuda()
+    _lib.call('bdn_tversky', lg_d.data_ptr(), lb_d.data_ptr(), 0.1, 0.9, 1e-7, ws.data_ptr(), loss.data_ptr(),
+              None, dl.data_ptr(), B, ncls, H, W, st())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g['tversky_0.1_0.9_r3'])) < 2e-6
+    assert_close('dlogits', dl.cpu(), torch.from_numpy(g['dlogits_tversky_r3']), 2e-4)
+
+
+# ------------------------------------------------------------------ converters, SGD
+@pytest.mark.parametrize('prec', PRECS)
+def test_pack_input_and_weights(prec):
+    dt, td = DT[prec]
+    B, C, H, W, Cp = 2, 13, 9, 7, 16
+    x1, x2 = _rand((B, C, H, W), 81), _rand((B, C, H, W), 82)
+    out = torch.empty(2 * B, H, W, Cp, dtype=td, device='cuda')
+    a, b = dev(x1), dev(x2)
+    _lib.call('bdn_pack_input', dt, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, C, H, W, Cp, st())
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    ref = rnd(prec, torch.cat([x1, x2]))
+    assert torch.equal(got[:, :C], ref) and (got[:, C:] == 0).all()
+    w = _rand((64, C, 3, 3), 83)
+    wf, wd = pack_w(prec, w, Cp)
+    torch.cuda.synchronize()
+    wr = rnd(prec, w)
+    assert torch.equal(wf.float().cpu()[:, :, :C], wr.permute(0, 2, 3, 1).reshape(64, 9, C))
+    assert (wf.float().cpu()[:, :, C:] == 0).all()
+    rot = torch.flip(wr, (2, 3)).permute(1, 2, 3, 0).reshape(C, 9, 64)
+    assert torch.equal(wd.float().cpu()[:C], rot)
+
+
+def test_sgd_step():
+    n = 1000003
+    p, g = _rand((n,), 91), _rand((n,), 92)
+    pd, gd = dev(p), dev(g)
+    _lib.call('bdn_sgd_step', pd.data_ptr(), gd.data_ptr(), 1e-3, 0.5, n, st())
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), p - 1e-3 * 0.5 * g, atol=1e-6, rtol=0)

@@ -1,0 +1,154 @@
+"""-m gpu whole-model parity: fabric_amd.BiDateNet on the HIP library vs golden vectors captured from
+the reference itself (tests/golden, oracle/make_golden.py) through the drop-in module surface:
+BiDateNet(n_channels, n_classes), forward(x_d1, x_d2), autograd backward, torch.optim.SGD.
+
+Stated tolerances:
+  fp32 setting : per-pixel logits within 1e-3 of the reference (train mode), identical argmax except
+                 where the reference's own top-2 margin is < 2e-3, loss within 1e-5, BatchNorm running
+                 buffers within 1e-4, weight gradients within 2e-2 relative L2 (two float32
+                 implementations differ by ~2e-3 already, see oracle/make_golden.py).
+  bf16 setting : max |dlogit| <= 0.25, mean |dlogit| <= 0.03, argmax agreement >= 96 %, loss within
+                 5e-3.  Gradients: the REFERENCE ITSELF under torch.autocast(bfloat16) deviates from its
+                 own float32 gradients by 0.30-0.43 relative L2 on the deep encoder parameters (median
+                 0.25-0.30 over parameters, whole-vector cosine 0.99; measured in the build container, see
+                 DESIGN.md "tolerances"), so the bound here is per-parameter relative L2 <= 0.8 on the
+                 sampled entries and cosine >= 0.97 over all sampled entries.  Kernel-level bf16
+                 correctness is pinned separately and tightly in test_gpu_kernels.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fabric_amd import BiDateNet
+from oracle import filler
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['g1_c3_b4_s32', 'g2_c13_b2_s128', 'g4_c13_b2_s90', 'g6_c3_b4_s32_diffdates', 'g8_c13_b3_h40_w72']
+
+
+def _load(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    c, b, s, sw, dd = [int(v) for v in g['meta']]
+    x1, x2, lbl = filler.make_inputs(b, c, s, seed=0, different_dates=bool(dd), size_w=sw)
+    return g, c, torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), torch.from_numpy(lbl).cuda()
+
+
+def _tversky_torch(logits, labels, alpha=0.1, beta=0.9, eps=1e-7):
+    # plain torch restatement of train.py's criterion so the test exercises BiDateNet's own autograd node
+    from oracle.bidate_oracle import tversky_loss
+    lg = logits
+    true = labels.long()
+    nc = lg.shape[1]
+    one_hot = torch.eye(nc, device=lg.device)[true].permute(0, 3, 1, 2)
+    probas = torch.softmax(lg, dim=1)
+    dims = (0, 2)
+    inter = torch.sum(probas * one_hot, dims)
+    fps = torch.sum(probas * (1 - one_hot), dims)
+    fns = torch.sum((1 - probas) * one_hot, dims)
+    return 1 - (inter / (inter + alpha * fps + beta * fns + eps)).mean()
+
+
+def _grad_errors(model, g):
+    """relative L2 error of the sampled gradient entries per parameter, and of the norms."""
+    worst, worst_key = 0.0, None
+    allg, allr = [], []
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g['gsamp/' + k]).double()
+        refnorm = float(g['gnorm/' + k])
+        if refnorm < 1e-6:          # conv biases feeding a BatchNorm: reference holds only rounding noise (~1e-9)
+            assert float(p.grad.norm()) < 1e-6, k
+            continue
+        got = p.grad.detach().reshape(-1).cpu().double()[torch.from_numpy(g['gidx/' + k])]
+        rel = float((got - ref).norm() / (ref.norm() + 1e-30))
+        allg.append(got)
+        allr.append(ref)
+        nrel = abs(float(p.grad.double().norm()) - refnorm) / refnorm
+        e = max(rel, nrel)
+        if e > worst:
+            worst, worst_key = e, k
+    ag, ar = torch.cat(allg), torch.cat(allr)
+    cos = float((ag * ar).sum() / (ag.norm() * ar.norm()))
+    return worst, worst_key, cos
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_train_step_matches_reference(golden_dir, name, prec):
+    g, c, x1, x2, lbl = _load(golden_dir, name)
+    model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda()
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)           # train.py:55
+    opt.zero_grad()
+    logits = model(x1, x2)                                        # train.py:91
+    loss = _tversky_torch(logits, lbl)                            # train.py:92
+    loss.backward()                                               # train.py:94
+    ref = torch.from_numpy(g['logits'])
+    got = logits.detach().cpu()
+    d = (got - ref).abs()
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    gerr, gkey, gcos = _grad_errors(model, g)
+    print(f'\n[{name} {prec}] max|dlogit|={d.max():.3e} mean={d.mean():.3e} argmax agree={agree:.4f} '
+          f'loss={loss.item():.6f} (ref {float(g["loss"]):.6f}) worst grad err={gerr:.3e} @ {gkey} cos={gcos:.4f}')
+    if prec == 'fp32':
+        assert d.max() <= 1e-3
+        margin = (ref[:, 0] - ref[:, 1]).abs()
+        assert ((got.argmax(1) == ref.argmax(1)) | (margin < 2e-3)).all()
+        assert abs(loss.item() - float(g['loss'])) < 1e-5
+        assert gerr < 2e-2 and gcos > 0.9999, (gkey, gerr, gcos)
+    else:
+        assert d.max() <= 0.25 and d.mean() <= 0.03
+        assert agree >= 0.96
+        assert abs(loss.item() - float(g['loss'])) < 5e-3
+        assert gerr < 0.8 and gcos >= 0.97, (gkey, gerr, gcos)
+    # BatchNorm running buffers after ONE forward: updated twice (date 1 then date 2)
+    sd = model.state_dict()
+    btol = 1e-4 if prec == 'fp32' else 2e-2
+    for k in sd:
+        if 'running_' in k:
+            ref_b = torch.from_numpy(g['buf/' + k])
+            assert (sd[k].cpu() - ref_b).abs().max() <= btol * max(1.0, ref_b.abs().max().item()), k
+        if 'num_batches_tracked' in k:      # shared encoder BN modules run once per date, decoder ones once
+            assert int(sd[k]) == (1 if k.startswith('up') else 2), k
+    # one SGD step with torch's own optimizer, then forward again (train mode)
+    opt.step()
+    logits2 = model(x1, x2).detach().cpu()
+    d2 = (logits2 - torch.from_numpy(g['logits_after_step'])).abs()
+    assert d2.max() <= (1e-3 if prec == 'fp32' else 0.25)
+
+
+@pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_eval_mode_matches_reference(golden_dir, name, prec):
+    g, c, x1, x2, _ = _load(golden_dir, name)
+    model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda().eval()
+    with torch.no_grad():
+        got = model(x1, x2).cpu()
+    ref = torch.from_numpy(g['eval_logits'])
+    scale = ref.abs().max().item()             # the filler's running statistics give O(100) eval logits
+    d = (got - ref).abs().max().item()
+    print(f'\n[{name} {prec} eval] max|dlogit|={d:.3e} of scale {scale:.1f}')
+    assert d <= (2e-5 if prec == 'fp32' else 3e-2) * scale
+    sd = model.state_dict()
+    assert all(int(sd[k]) == 0 for k in sd if 'num_batches_tracked' in k)    # eval must not touch the buffers
+
+
+def test_cpu_tensors_are_refused():
+    model = BiDateNet(3, 2)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
+
+
+def test_f1_definition_on_device_counts(golden_dir):
+    """train.py:103-106 per-batch binary P/R/F1 from the on-device TP/FP/FN counts (G1's prf fixture)."""
+    from fabric_amd.utils.metrics import batch_prf_from_counts, TverskyLoss
+    g, c, x1, x2, lbl = _load(golden_dir, 'g1_c3_b4_s32')
+    model = filler.fill_module(BiDateNet(c, 2, precision='fp32')).cuda().train()
+    logits = model(x1, x2)
+    crit = TverskyLoss(alpha=0.1, beta=0.9)
+    loss = crit(logits, lbl.long())
+    assert abs(loss.item() - float(g['loss'])) < 1e-5
+    p, r, f = batch_prf_from_counts(crit.last_counts)
+    assert np.allclose([p, r, f], g['prf'], atol=2e-3)
