@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Headline benchmark: patch-pairs/s of one BiDateNet(13, 2) training step (forward + Tversky +
+backward + gradient all-reduce + SGD) on synthetic 13-band 128x128 patch pairs, batch 64 per GPU
+(BASELINE.json configs[1]; configs[2] = the same per-GPU work on N GPUs, weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- the dominant kernel (largest summed time of the conv3x3_kernel instantiations, i.e.
+                  3x3 forward + data-gradient launches): algorithmic FLOP per launch / average launch
+                  time measured with HIP events on the launch stream inside the timed region,
+                  against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md);
+  cpu_baseline -- the oracle's stock-torch assembly of the reference graph timed on this box's host
+                  cores (rank 0, N=1 only; bounded sample).  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR_FWD_BWD = 69.43e9
+MFMA_BF16_PEAK = 2.5e15                  # dense, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Reference CPU path (oracle port) on the host cores: fwd + Tversky + bwd + SGD, fp32, B=16."""
+    from oracle import bidate_oracle as O
+    from oracle import filler
+    ncores = os.cpu_count() or 1
+    threads = min(ncores, 64)
+    torch.set_num_threads(threads)
+    B = 16
+    x1, x2, lbl = filler.make_inputs(B, 13, 128, seed=0)
+    x1, x2, lbl = torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl).long()
+    net = O.build_torch_baseline(13, 2).train()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        loss = O.tversky_loss(net(x1, x2), lbl, 0.1, 0.9)
+        loss.backward()
+        opt.step()
+
+    step()                                   # warm-up (oneDNN primitive creation)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < seconds_budget:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': B / med, 'unit': 'patch-pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{len(times)} steps of B={B} 13x128x128 fwd+Tversky+bwd+SGD, fp32 stock torch.nn '
+                      f'assembly of the reference graph (oracle.build_torch_baseline), median; '
+                      f'{threads} threads of {ncores} host CPUs'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='patch pairs per GPU')
+    ap.add_argument('--size', type=int, default=128)
+    ap.add_argument('--channels', type=int, default=13)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP events')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (MI355X); there is no CPU path for the product')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from fabric_amd import BiDateNet
+    from fabric_amd.train_step import TrainStep
+
+    torch.manual_seed(1234)                  # same random-init weights on every rank
+    model = BiDateNet(args.channels, 2, precision=args.precision).to(dev).train()
+    ts = TrainStep(model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9)
+    g = torch.Generator(device='cpu').manual_seed(100 + rank)     # each rank its own shard of synthetic pairs
+    B, S, C = args.batch, args.size, args.channels
+    x1 = torch.randn(B, C, S, S, generator=g)
+    x2 = x1 + 0.3 * torch.randn(B, C, S, S, generator=g)
+    lbl = (torch.rand(B, S, S, generator=g) < 0.1).to(torch.uint8)
+    x1, x2, lbl = x1.to(dev), x2.to(dev), lbl.to(dev)     # resident in HBM before the timed region
+
+    for _ in range(args.warmup):
+        ts.step(x1, x2, lbl)
+    eng = model.engine()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_roofline:
+        eng.prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(x1, x2, lbl)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, eng.prof = eng.prof, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    roofline = None
+    if prof:
+        agg = {}
+        for name, flops, e0, e1 in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        name, (cnt, flops, secs) = max(agg.items(), key=lambda kv: kv[1][2])
+        peak = MFMA_BF16_PEAK if args.precision == 'bf16' else MFMA_F32_PEAK
+        achieved = flops / secs
+        conv_total = sum(v[2] for v in agg.values())
+        roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved / 1e12, 'peak': peak / 1e12,
+                    'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                    'launches_per_step': cnt / args.steps, 'avg_launch_us': secs / cnt * 1e6,
+                    'flop_per_launch': flops / cnt,
+                    'all_conv3x3_launches': {'time_frac_of_step': conv_total / elapsed,
+                                             'achieved': sum(v[1] for v in agg.values()) / conv_total / 1e12}}
+    if rank == 0:
+        pairs = args.steps * B * world
+        value = pairs / elapsed
+        out = {
+            'metric': 'patch-pairs/sec (fwd+bwd) 13-band 128x128', 'value': value, 'unit': 'patch-pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': f'BiDateNet({C},2) {C}-band {S}x{S} patch pairs, batch {B}/GPU, '
+                                   f'fwd + Tversky + bwd + grad all-reduce + SGD (BASELINE configs[{1 if world == 1 else 2}])',
+                       'global_batch': B * world, 'patch': S, 'bands': C,
+                       'parallelism': f'dp{world}', 'precision': args.precision},
+            'step_mfma_frac': value * FLOP_PER_PAIR_FWD_BWD / (world * (MFMA_BF16_PEAK if args.precision == 'bf16' else MFMA_F32_PEAK)),
+            'final_loss': loss_val,
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

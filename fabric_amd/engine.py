@@ -150,7 +150,30 @@ class BiDateEngine:
         self.layers = build_layers(n_channels)
         self._ws = {}
         self._packed = {}          # conv prefix -> (version key, wf, wd)
+        self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
+
+    # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
+    def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg):
+        """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to (csrc/conv3x3.hip)."""
+        ti, th, tw = (2, 8, 8) if (w <= 8 and h <= 8 and ipg % 2 == 0) else (1, 8, 16)
+        bn = 128 if cout % 128 == 0 else 64
+        if self.precision == 'bf16':
+            t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
+        else:
+            t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
+        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},2,2>'
+
+    def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args):
+        if self.prof is None:
+            call('bdn_conv3x3', *args)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call('bdn_conv3x3', *args)
+        e1.record()
+        self.prof.append((self.conv_kernel_name(n, h, w, c0, c1, cout, ipg),
+                          2.0 * n * h * w * cout * 9 * (c0 + c1), e0, e1))
 
     # ------------------------------------------------------------------ helpers
     def workspace(self, B, H, W, device):
@@ -178,9 +201,10 @@ class BiDateEngine:
         hk, wk = ws.dims[L.level - 1]
         wf, _ = self._weights(L, P, False)
         z = ws.z[L.name]
-        call('bdn_conv3x3', self.dt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
-             ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
-             n, hk, wk, L.cout, st)
+        self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
+                         self.dt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
+                         ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
+                         n, hk, wk, L.cout, st)
         bn = ws.bn[L.name]
         G = n // ipg
         if training:
@@ -277,8 +301,9 @@ class BiDateEngine:
             hk, wk = ws.dims[L.level - 1]
             _, wd = self._weights(L, P, True)
             out = e(n, hk, wk, L.cin)
-            call('bdn_conv3x3', self.dt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
-                 ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
+            self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
+                             self.dt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
+                             ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
             return out
 
         # ---- classifier

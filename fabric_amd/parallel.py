@@ -1,0 +1,115 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI.
+
+Replaces the reference's single-process nn.DataParallel wrap (utils/helpers.py:333-335:
+per-forward parameter broadcast + scatter/gather) with the DDP pattern: every rank holds the
+full model, patch-pair batches are sharded across ranks, BatchNorm statistics stay local
+(exactly what DataParallel's replicas do), and the 53.6 MB of float32 gradients are summed
+with a handful of bucketed all-reduces launched from inside backward, so the collectives run
+on RCCL's stream while the remaining dgrad / wgrad kernels keep the compute stream busy.
+
+The gradients live in ONE flat buffer laid out in the order they complete during backward
+(engine.param_order), so a bucket is a contiguous slice and needs no packing copy.  xGMI is
+point to point (7 links per GPU): a ring all-reduce is bound by one link, so buckets are kept
+large (default 4 slices of ~13 MB) rather than many small NVSwitch-style ones.
+
+This module is pure torch.distributed logic and runs unchanged on CPU tensors with the gloo
+backend (tests/test_parallel_cpu.py, world_size 2).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatLayout:
+    """Offsets of every parameter inside the flat parameter / gradient buffers."""
+
+    def __init__(self, named_shapes, order):
+        shapes = dict(named_shapes)
+        assert set(order) == set(shapes), 'param order must cover exactly the model parameters'
+        self.order = list(order)
+        self.slices = {}
+        off = 0
+        for k in self.order:
+            n = 1
+            for d in shapes[k]:
+                n *= d
+            n_pad = (n + 3) // 4 * 4                     # keep every tensor 16-byte aligned
+            self.slices[k] = (off, n, tuple(shapes[k]))
+            off += n_pad
+        self.total = off
+
+    def view(self, flat, key):
+        off, n, shape = self.slices[key]
+        return flat[off:off + n].view(shape)
+
+
+class GradBucketer:
+    """Launches an async all-reduce on a contiguous slice of the flat gradient buffer as soon as every
+    gradient inside it has been produced.
+
+    keys_no_reduce: gradients that are identically zero on every rank (conv biases in front of a
+    BatchNorm) -- they sit at the tail of the layout and are never communicated."""
+
+    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=()):
+        self.layout, self.flat, self.group = layout, flat_grads, group
+        skip = set(keys_no_reduce)
+        keys = [k for k in layout.order if k not in skip]
+        assert keys == layout.order[:len(keys)], 'non-reduced gradients must form the tail of the layout'
+        end = 0
+        for k in keys:
+            off, n, _ = layout.slices[k]
+            end = max(end, off + n)
+        self.reduce_end = (end + 3) // 4 * 4
+        target = max(1, self.reduce_end // max(1, n_buckets))
+        self.buckets = []                                # (start, stop, [keys])
+        cur, start = [], 0
+        for k in keys:
+            off, n, _ = layout.slices[k]
+            cur.append(k)
+            stop = (off + n + 3) // 4 * 4
+            if stop - start >= target and len(self.buckets) < n_buckets - 1:
+                self.buckets.append((start, stop, cur))
+                cur, start = [], stop
+        if cur:
+            self.buckets.append((start, self.reduce_end, cur))
+        self.key_bucket = {k: i for i, (_, _, ks) in enumerate(self.buckets) for k in ks}
+        self.reset()
+
+    def reset(self):
+        self.pending = [set(ks) for _, _, ks in self.buckets]
+        self.works = []
+        self.launched = [False] * len(self.buckets)
+
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def on_ready(self, keys):
+        """Backward hook: `keys` have just been enqueued on the current stream."""
+        if self.world_size() == 1:
+            return
+        for k in keys:
+            i = self.key_bucket.get(k)
+            if i is None:
+                continue
+            self.pending[i].discard(k)
+            if not self.pending[i] and not self.launched[i]:
+                a, b, _ = self.buckets[i]
+                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.launched[i] = True
+
+    def finish(self):
+        """Launch whatever is left and make the current stream wait for every bucket."""
+        if self.world_size() > 1:
+            for i, (a, b, _) in enumerate(self.buckets):
+                if not self.launched[i]:
+                    self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.launched[i] = True
+            for w in self.works:
+                w.wait()
+        self.reset()
+
+
+def shard_indices(n_items, rank, world_size):
+    """Disjoint stride-by-rank shard of a (shuffled) patch index list; every rank gets the same count
+    (the tail is dropped) so all ranks run the same number of steps."""
+    per = n_items // world_size
+    return list(range(rank, per * world_size, world_size))
