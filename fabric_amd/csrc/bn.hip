@@ -1,0 +1,269 @@
+// BatchNorm2d (reference models/unet_parts.py:14,17) pieces that are not fused into a convolution:
+//   * finalize: per-tile sum / sum^2 partials written by the conv epilogue -> per-(group, channel)
+//     mean / invstd / scale / shift table + running-statistics update;
+//   * backward of BatchNorm+ReLU: masked reductions (sum g, sum g*xhat), then
+//     dz = scale * (g - s0/M - xhat*s1/M).
+// HBM-bound streaming kernels: every thread owns one 16-byte channel unit and walks pixels, so the
+// per-channel constants live in registers; reductions go through per-block partials in a fixed order
+// (deterministic, no atomics) and are summed in double.
+#include "common.hpp"
+
+static inline unsigned grid_for(size_t n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// ---------------------------------------------------------------- row reduction helpers
+// partial: [n_rows][2][C] f32.  Stage A (many rows): grid (ceil(C/64), G, RS), 256 threads = 4 row lanes x 64
+// channels; block (cb, g, s) sums rows [s*rps, (s+1)*rps) of group g in double -> part2[g][s][2][C].
+__global__ void reduce_rows_kernel(const float* __restrict__ partial, int rows_per_group, int rps, int RS, int C,
+                                   double* __restrict__ part2) {
+    __shared__ double sm[4][64][2];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, g = blockIdx.y, s = blockIdx.z;
+    const int r0 = s * rps, r1 = min(rows_per_group, r0 + rps);
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t row = (size_t)g * rows_per_group + r;
+            a0 += partial[(row * 2 + 0) * C + c];
+            a1 += partial[(row * 2 + 1) * C + c];
+        }
+    sm[rl][cl][0] = a0; sm[rl][cl][1] = a1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 4; k++) { a0 += sm[k][cl][0]; a1 += sm[k][cl][1]; }
+        part2[(((size_t)g * RS + s) * 2 + 0) * C + c] = a0;
+        part2[(((size_t)g * RS + s) * 2 + 1) * C + c] = a1;
+    }
+}
+
+struct RowPlan { int RS, rps; };
+static inline RowPlan row_plan(int rows_per_group) {
+    RowPlan p;
+    p.RS = (rows_per_group + 127) / 128;
+    if (p.RS > 64) p.RS = 64;
+    if (p.RS < 1) p.RS = 1;
+    p.rps = (rows_per_group + p.RS - 1) / p.RS;
+    p.RS = (rows_per_group + p.rps - 1) / p.rps;
+    return p;
+}
+
+// ---------------------------------------------------------------- finalize (training statistics)
+__global__ void bn_finalize_kernel(const double* __restrict__ part2, int RS, int G, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* nbt, float* __restrict__ bn) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+        for (int g = 0; g < G; g++) {                     // sequential: running stats see date 1 then date 2
+            double s0 = 0.0, s1 = 0.0;
+            for (int s = 0; s < RS; s++) {
+                s0 += part2[(((size_t)g * RS + s) * 2 + 0) * C + c];
+                s1 += part2[(((size_t)g * RS + s) * 2 + 1) * C + c];
+            }
+            const double mean = s0 / count;
+            double var = s1 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float inv = (float)(1.0 / sqrt(var + (double)eps));
+            const float scale = gamma[c] * inv;
+            bn[((size_t)g * 4 + 0) * C + c] = (float)mean;
+            bn[((size_t)g * 4 + 1) * C + c] = inv;
+            bn[((size_t)g * 4 + 2) * C + c] = scale;
+            bn[((size_t)g * 4 + 3) * C + c] = beta[c] - (float)mean * scale;
+            const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * (float)unb;
+        }
+        if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += G;
+}
+
+extern "C" size_t bdn_bn_finalize_workspace_bytes(int n_mtiles, int G, int C) {
+    if (n_mtiles <= 0 || G <= 0 || C <= 0) return 0;
+    return (size_t)G * 64 * 2 * C * sizeof(double);
+}
+
+extern "C" int bdn_bn_finalize(const float* stats_partial, int n_mtiles, int G, int C, int count_per_group,
+                               const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* bn, void* ws, void* stream) {
+    if (!stats_partial || !gamma || !beta || !bn || !ws) BDN_FAIL(BDN_E_ARG, "bn_finalize: null pointer");
+    if (G <= 0 || C <= 0 || n_mtiles <= 0 || n_mtiles % G || count_per_group <= 0) BDN_FAIL(BDN_E_SHAPE, "bn_finalize: bad shape");
+    if ((running_mean == nullptr) != (running_var == nullptr)) BDN_FAIL(BDN_E_ARG, "bn_finalize: running_mean/var must come together");
+    hipStream_t st = (hipStream_t)stream;
+    const int rpg = n_mtiles / G;
+    const RowPlan p = row_plan(rpg);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64, G, p.RS), dim3(256), 0, st, stats_partial, rpg, p.rps, p.RS, C, (double*)ws);
+    BDN_CHECK_LAUNCH("bn_reduce_rows");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const double*)ws, p.RS, G, C, (double)count_per_group,
+                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, bn);
+    BDN_CHECK_LAUNCH("bn_finalize");
+    return BDN_OK;
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               int G, int C, float* bn) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    const float scale = gamma[c] * inv;
+    for (int g = 0; g < G; g++) {
+        bn[((size_t)g * 4 + 0) * C + c] = rm[c];
+        bn[((size_t)g * 4 + 1) * C + c] = inv;
+        bn[((size_t)g * 4 + 2) * C + c] = scale;
+        bn[((size_t)g * 4 + 3) * C + c] = beta[c] - rm[c] * scale;
+    }
+}
+
+extern "C" int bdn_bn_eval(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, int G, int C, float* bn, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !bn) BDN_FAIL(BDN_E_ARG, "bn_eval: null pointer");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, running_mean, running_var, eps, G, C, bn);
+    BDN_CHECK_LAUNCH("bn_eval");
+    return BDN_OK;
+}
+
+// ---------------------------------------------------------------- backward (BatchNorm2d + ReLU)
+// Thread t owns channel unit t % CU and pixel lane t / CU (CU = C / EPU divides 256); a block covers
+// BNB_PIX pixels of ONE group.
+constexpr int BNB_PIX = 2048;
+
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
+                                     int pix_per_group, int blocks_per_group, int C, float* __restrict__ partial) {
+    constexpr int EPU = ET<T>::EPU;
+    extern __shared__ float sred[];                           // [256][EPU][2]
+    const int CU = C / EPU, rows = 256 / CU;
+    const int g = blockIdx.x / blocks_per_group, bg = blockIdx.x % blocks_per_group;
+    const int p_begin = bg * BNB_PIX, p_end = min(pix_per_group, p_begin + BNB_PIX);
+    const int tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    float s0[EPU], s1[EPU], mean[EPU], inv[EPU], sc[EPU], sh[EPU];
+#pragma unroll
+    for (int i = 0; i < EPU; i++) {
+        s0[i] = 0.f; s1[i] = 0.f;
+        mean[i] = bn_row(bn, g, 0, C)[c + i]; inv[i] = bn_row(bn, g, 1, C)[c + i];
+        sc[i] = bn_row(bn, g, 2, C)[c + i]; sh[i] = bn_row(bn, g, 3, C)[c + i];
+    }
+    for (int p = p_begin + row; p < p_end; p += rows) {
+        const size_t pix = (size_t)g * pix_per_group + p;
+        float fz[EPU], fg[EPU];
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + pix * C + c), fz);
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(dA + pix * ldA + c), fg);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            const float gm = fmaf(fz[i], sc[i], sh[i]) > 0.f ? fg[i] : 0.f;
+            s0[i] += gm; s1[i] += gm * ((fz[i] - mean[i]) * inv[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EPU; i++) { sred[(tid * EPU + i) * 2] = s0[i]; sred[(tid * EPU + i) * 2 + 1] = s1[i]; }
+    __syncthreads();
+    for (int o = tid; o < C * 2; o += 256) {
+        const int k = o & 1, cc = o >> 1, ccu = cc / EPU, i = cc % EPU;
+        float s = 0.f;
+        for (int r = 0; r < rows; r++) s += sred[((r * CU + ccu) * EPU + i) * 2 + k];
+        partial[((size_t)blockIdx.x * 2 + k) * C + cc] = s;
+    }
+}
+
+// reduce the per-block partials -> sums[g][2][C]; dgamma / dbeta are summed over groups
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks_per_group, int G, int C,
+                                       float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sm[16][16][2];
+    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + cl;
+    double t0 = 0.0, t1 = 0.0;
+    for (int g = 0; g < G; g++) {
+        double a0 = 0.0, a1 = 0.0;
+        if (c < C)
+            for (int r = rl; r < blocks_per_group; r += 16) {
+                const size_t row = (size_t)g * blocks_per_group + r;
+                a0 += partial[(row * 2 + 0) * C + c];
+                a1 += partial[(row * 2 + 1) * C + c];
+            }
+        sm[rl][cl][0] = a0; sm[rl][cl][1] = a1;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            for (int r = 1; r < 16; r++) { a0 += sm[r][cl][0]; a1 += sm[r][cl][1]; }
+            sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
+            sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
+            t0 += a0; t1 += a1;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < C) {
+        if (dbeta) dbeta[c] = (float)t0;
+        if (dgamma) dgamma[c] = (float)t1;
+    }
+}
+
+// dz = scale * (g - s0/M - xhat * s1/M)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
+                                    const float* __restrict__ sums, int pix_per_group, int blocks_per_group, int C,
+                                    T* __restrict__ dz) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU;
+    const int g = blockIdx.x / blocks_per_group, bg = blockIdx.x % blocks_per_group;
+    const int p_begin = bg * BNB_PIX, p_end = min(pix_per_group, p_begin + BNB_PIX);
+    const int tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const float invM = 1.f / (float)pix_per_group;
+    float mean[EPU], inv[EPU], sc[EPU], sh[EPU], k0[EPU], k1[EPU];
+#pragma unroll
+    for (int i = 0; i < EPU; i++) {
+        mean[i] = bn_row(bn, g, 0, C)[c + i]; inv[i] = bn_row(bn, g, 1, C)[c + i];
+        sc[i] = bn_row(bn, g, 2, C)[c + i]; sh[i] = bn_row(bn, g, 3, C)[c + i];
+        k0[i] = sums[((size_t)g * 2 + 0) * C + c + i] * invM;
+        k1[i] = sums[((size_t)g * 2 + 1) * C + c + i] * invM;
+    }
+    for (int p = p_begin + row; p < p_end; p += rows) {
+        const size_t pix = (size_t)g * pix_per_group + p;
+        float fz[EPU], fg[EPU], o[EPU];
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + pix * C + c), fz);
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(dA + pix * ldA + c), fg);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            const float gm = fmaf(fz[i], sc[i], sh[i]) > 0.f ? fg[i] : 0.f;
+            const float xhat = (fz[i] - mean[i]) * inv[i];
+            o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
+        }
+        *reinterpret_cast<uint4*>(dz + pix * C + c) = Unit<T>::pack(o);
+    }
+}
+
+static inline int bnb_blocks_per_group(int pix_per_group) { return (pix_per_group + BNB_PIX - 1) / BNB_PIX; }
+
+extern "C" size_t bdn_bn_bwd_workspace_bytes(int N, int H, int W, int C) {
+    // blocks never straddle groups: bound with one group per image
+    size_t blocks = (size_t)N * bnb_blocks_per_group(H * W) + 2;
+    return blocks * 2 * C * sizeof(float);
+}
+
+template <typename T>
+static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, int imgs_per_group,
+                       int N, int H, int W, int C, float* ws, float* sums, float* dgamma, float* dbeta, void* dz, hipStream_t st) {
+    constexpr int EPU = ET<T>::EPU;
+    const int G = N / imgs_per_group;
+    const int ppg = imgs_per_group * H * W;
+    const int bpg = bnb_blocks_per_group(ppg);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(G * bpg), dim3(256), 256 * EPU * 2 * sizeof(float), st,
+                       (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, C, ws);
+    BDN_CHECK_LAUNCH("bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, bpg, G, C, sums, dgamma, dbeta);
+    BDN_CHECK_LAUNCH("bn_bwd_finalize");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
+                       (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, C, (T*)dz);
+    BDN_CHECK_LAUNCH("bn_bwd_apply");
+    return BDN_OK;
+}
+
+extern "C" int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* bn,
+                          int imgs_per_group, int N, int H, int W, int C,
+                          float* ws, float* sums, float* dgamma, float* dbeta, void* dz, void* stream) {
+    if (!dA || !z || !bn || !ws || !sums || !dz) BDN_FAIL(BDN_E_ARG, "bn_bwd: null pointer");
+    if (N <= 0 || imgs_per_group <= 0 || N % imgs_per_group || C % 16 || ldA < C || ldA % 16) BDN_FAIL(BDN_E_SHAPE, "bn_bwd: bad shape");
+    if (C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "bn_bwd: C=%d must divide 1024", C);
+    if (dtype == BDN_BF16) return bn_bwd_impl<bf16s>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, ws, sums, dgamma, dbeta, dz, (hipStream_t)stream);
+    if (dtype == BDN_F32) return bn_bwd_impl<float>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, ws, sums, dgamma, dbeta, dz, (hipStream_t)stream);
+    BDN_FAIL(BDN_E_ARG, "bn_bwd: bad dtype");
+}

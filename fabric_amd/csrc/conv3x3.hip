@@ -103,27 +103,28 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             for (int r = 0; r < 16; r++) acc[mi][nj][r] = 0.f;
 
     const T* wbase = reinterpret_cast<const T*>(a.w);
+    // filter slice of one (tap, chunk): BN rows x CKB bytes, NWU 16-byte units per thread, held in registers
+    // between the global load (issued before the MFMAs of the previous tap) and the LDS store (after them).
+    // Plain unrolled code on purpose: a lambda capturing the register array by reference sent it to scratch.
+    constexpr bool W_EXACT = (BN * UPP) % 256 == 0;
     uint4 wreg[NWU];
-    auto load_w = [&](int tap, int c0) {
+    const T* wsrc[NWU];
+    int wdst[NWU];
 #pragma unroll
-        for (int i = 0; i < NWU; i++) {
-            int u = tid + i * 256;
-            if (u < BN * UPP) {
-                int row = u / UPP, sub = u % UPP;
-                wreg[i] = *reinterpret_cast<const uint4*>(wbase + ((size_t)(col0 + row) * 9 + tap) * Cin + c0 + sub * EPU);
-            }
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NWU; i++) {
-            int u = tid + i * 256;
-            if (u < BN * UPP) {
-                int row = u / UPP, sub = u % UPP;
-                *reinterpret_cast<uint4*>(wbuf + buf * CF::WBUF_BYTES + row * WSTR + sub * 16) = wreg[i];
-            }
-        }
-    };
+    for (int i = 0; i < NWU; i++) {
+        const int u = tid + i * 256;
+        const int row = (W_EXACT || u < BN * UPP) ? u / UPP : 0, sub = u % UPP;
+        wsrc[i] = wbase + (size_t)(col0 + row) * 9 * Cin + sub * EPU;
+        wdst[i] = row * WSTR + sub * 16;
+    }
+#define LOAD_W(tap_, c0_)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NWU; i++)                                                     \
+        if (W_EXACT || tid + i * 256 < BN * UPP)                                                        \
+            wreg[i] = *reinterpret_cast<const uint4*>(wsrc[i] + (size_t)(tap_) * Cin + (c0_));
+#define STORE_W(buf_)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NWU; i++)                                                     \
+        if (W_EXACT || tid + i * 256 < BN * UPP)                                                        \
+            *reinterpret_cast<uint4*>(wbuf + (buf_) * CF::WBUF_BYTES + wdst[i]) = wreg[i];
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         // ---- stage the activation patch of this channel chunk (LDS free: previous chunk ended with a barrier)
@@ -137,12 +138,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             }
             stage_patch<T, CKB, PSTR, TH, TW, TI>(patch, src, Csrc, cs, CK, sc, sh, n0, y0, x0, a.N, a.H, a.W, tid);
         }
-        load_w(0, c0);
-        store_w(0);
+        LOAD_W(0, c0)
+        STORE_W(0)
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            if (tap < 8) load_w(tap + 1, c0);                    // global -> regs, in flight during the MFMAs
+            if (tap < 8) { LOAD_W(tap + 1, c0) }                 // global -> regs, in flight during the MFMAs
             const unsigned char* wb = wbuf + (tap & 1) * CF::WBUF_BYTES;
             const int tapoff = ((tap / 3) * TL::PW + (tap % 3)) * PSTR;
 #pragma unroll
@@ -157,10 +158,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                     for (int nj = 0; nj < NJ; nj++) Mma<T>::run(af[mi], bf[nj], acc[mi][nj]);
             }
-            if (tap < 8) store_w((tap + 1) & 1);                 // other buffer: last read before the previous barrier
+            if (tap < 8) { STORE_W((tap + 1) & 1) }              // other buffer: last read before the previous barrier
             __syncthreads();
         }
     }
+#undef LOAD_W
+#undef STORE_W
 
     // ------------------------------------------------------------------ epilogue (LDS reused)
     unsigned char* otile = smem;

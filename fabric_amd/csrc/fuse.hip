@@ -1,0 +1,290 @@
+// Stage-boundary kernels between the convolutions (all HBM-bound, NHWC, 16-byte channel units):
+//   bnrelu_pool   nn.MaxPool2d(2) of relu(bn(z))                 reference models/unet_parts.py:40
+//   fuse_product  torch.relu(x_d2 * x_d1)                        reference models/bidate_model.py:35-38
+//   upsample2x    nn.Upsample(x2, bilinear, align_corners) + pad reference models/unet_parts.py:56-58,68-72
+//   ..._bwd       their backward gathers (no atomics: every output element gathers its contributions)
+// Every thread owns one channel unit (its BatchNorm scale/shift stay in registers) and walks pixels.
+#include "common.hpp"
+
+template <typename T>
+__device__ __forceinline__ void load_consts(const float* __restrict__ p, float (&o)[ET<T>::EPU]) {
+#pragma unroll
+    for (int i = 0; i < ET<T>::EPU; i++) o[i] = p[i];
+}
+// a = storage-rounded relu(z*sc+sh), exactly what the conv kernels feed the MFMA
+template <typename T>
+__device__ __forceinline__ float act1(float z, float sc, float sh) {
+    return to_f(from_f<T>(fmaxf(fmaf(z, sc, sh), 0.f)));
+}
+
+constexpr int ITERS = 8;        // pixels per thread
+
+// ============================================================ bnrelu + MaxPool2d(2)
+template <typename T>
+__global__ void bnrelu_pool_kernel(const T* __restrict__ z, const float* __restrict__ bn, int imgs_per_group, int bpg,
+                                   T* __restrict__ out, int H, int W, int C) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int Ho = H / 2, Wo = W / 2;
+    const int g = blockIdx.x / bpg, bg = blockIdx.x % bpg;
+    const int ppg = imgs_per_group * Ho * Wo;
+    float sc[EPU], sh[EPU];
+    load_consts<T>(bn_row(bn, g, 2, C) + c, sc); load_consts<T>(bn_row(bn, g, 3, C) + c, sh);
+    const int p_end = min(ppg, (bg + 1) * rows * ITERS);
+    for (int p = bg * rows * ITERS + row; p < p_end; p += rows) {
+        const int xo = p % Wo, t = p / Wo, yo = t % Ho, n = g * imgs_per_group + t / Ho;
+        float m[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) m[i] = 0.f;                 // post-ReLU values are >= 0
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float f[EPU];
+            Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)(n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c), f);
+#pragma unroll
+            for (int i = 0; i < EPU; i++) m[i] = fmaxf(m[i], act1<T>(f[i], sc[i], sh[i]));
+        }
+        *reinterpret_cast<uint4*>(out + ((size_t)(n * Ho + yo) * Wo + xo) * C + c) = Unit<T>::pack(m);
+    }
+}
+
+extern "C" int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_group,
+                               void* out, int N, int H, int W, int C, void* stream) {
+    if (!z || !bn || !out) BDN_FAIL(BDN_E_ARG, "bnrelu_pool: null pointer");
+    if (H < 2 || W < 2 || C % 16 || C > 1024 || 1024 % C || imgs_per_group <= 0 || N % imgs_per_group) BDN_FAIL(BDN_E_SHAPE, "bnrelu_pool: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int G = N / imgs_per_group, ppg = imgs_per_group * (H / 2) * (W / 2);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS, bpg = (ppg + per - 1) / per;
+        hipLaunchKernelGGL(bnrelu_pool_kernel<bf16s>, dim3(G * bpg), dim3(256), 0, st, (const bf16s*)z, bn, imgs_per_group, bpg, (bf16s*)out, H, W, C); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS, bpg = (ppg + per - 1) / per;
+        hipLaunchKernelGGL(bnrelu_pool_kernel<float>, dim3(G * bpg), dim3(256), 0, st, (const float*)z, bn, imgs_per_group, bpg, (float*)out, H, W, C); }
+    else BDN_FAIL(BDN_E_ARG, "bnrelu_pool: bad dtype");
+    BDN_CHECK_LAUNCH("bnrelu_pool");
+    return BDN_OK;
+}
+
+// ============================================================ date fusion relu(a_d2 * a_d1)
+template <typename T>
+__global__ void fuse_product_kernel(const T* __restrict__ z, const float* __restrict__ bn, T* __restrict__ f, int npix, int C) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    float sc0[EPU], sh0[EPU], sc1[EPU], sh1[EPU];
+    load_consts<T>(bn_row(bn, 0, 2, C) + c, sc0); load_consts<T>(bn_row(bn, 0, 3, C) + c, sh0);
+    load_consts<T>(bn_row(bn, 1, 2, C) + c, sc1); load_consts<T>(bn_row(bn, 1, 3, C) + c, sh1);
+    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * ITERS);
+    for (int p = blockIdx.x * rows * ITERS + row; p < p_end; p += rows) {
+        float a[EPU], b[EPU];
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), a);
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)npix + p) * C + c), b);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) a[i] = act1<T>(a[i], sc0[i], sh0[i]) * act1<T>(b[i], sc1[i], sh1[i]);   // >= 0: relu is a no-op
+        *reinterpret_cast<uint4*>(f + (size_t)p * C + c) = Unit<T>::pack(a);
+    }
+}
+
+extern "C" int bdn_fuse_product(int dtype, const void* z, const float* bn, void* f,
+                                int B, int H, int W, int C, void* stream) {
+    if (!z || !bn || !f) BDN_FAIL(BDN_E_ARG, "fuse_product: null pointer");
+    if (C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "fuse_product: bad C");
+    hipStream_t st = (hipStream_t)stream;
+    const int npix = B * H * W;
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS;
+        hipLaunchKernelGGL(fuse_product_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, npix, C); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS;
+        hipLaunchKernelGGL(fuse_product_kernel<float>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, npix, C); }
+    else BDN_FAIL(BDN_E_ARG, "fuse_product: bad dtype");
+    BDN_CHECK_LAUNCH("fuse_product");
+    return BDN_OK;
+}
+
+// ============================================================ bilinear x2 (align_corners=True) + F.pad
+// source index / weight of destination index d (ATen area_pixel_compute_source_index, align_corners)
+__device__ __forceinline__ void up_tap(int d, int n_in, float scale, int& i0, int& i1, float& lam) {
+    const float s = scale * (float)d;
+    i0 = (int)s; if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    lam = s - (float)i0;
+}
+static inline float up_scale(int n_in) { return n_in > 1 ? (float)(n_in - 1) / (float)(2 * n_in - 1) : 0.f; }
+
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ src, const float* __restrict__ bn, T* __restrict__ out,
+                                  int npix, int h, int w, int H, int W, int C, float sy, float sx) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int top = (H - 2 * h) / 2, left = (W - 2 * w) / 2;
+    float sc[EPU], sh[EPU];
+    if (bn) { load_consts<T>(bn_row(bn, 0, 2, C) + c, sc); load_consts<T>(bn_row(bn, 0, 3, C) + c, sh); }
+    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * ITERS);
+    for (int p = blockIdx.x * rows * ITERS + row; p < p_end; p += rows) {
+        const int X = p % W, t = p / W, Y = t % H, n = t / H;
+        const int yy = Y - top, xx = X - left;
+        float o[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) o[i] = 0.f;
+        if (yy >= 0 && yy < 2 * h && xx >= 0 && xx < 2 * w) {
+            int y0, y1, x0, x1; float ly, lx;
+            up_tap(yy, h, sy, y0, y1, ly); up_tap(xx, w, sx, x0, x1, lx);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ys = (k >> 1) ? y1 : y0, xs = (k & 1) ? x1 : x0;
+                const float wgt = ((k >> 1) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+                float f[EPU];
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(src + ((size_t)(n * h + ys) * w + xs) * C + c), f);
+#pragma unroll
+                for (int i = 0; i < EPU; i++) o[i] += wgt * (bn ? act1<T>(f[i], sc[i], sh[i]) : f[i]);
+            }
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)p * C + c) = Unit<T>::pack(o);
+    }
+}
+
+extern "C" int bdn_upsample2x(int dtype, const void* src, int in_mode, const float* bn,
+                              void* out, int B, int h, int w, int H, int W, int C, void* stream) {
+    if (!src || !out) BDN_FAIL(BDN_E_ARG, "upsample2x: null pointer");
+    if (in_mode == BDN_IN_BNRELU && !bn) BDN_FAIL(BDN_E_ARG, "upsample2x: BNRELU needs bn");
+    if (H < 2 * h || W < 2 * w || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "upsample2x: bad shape");
+    const float* b = in_mode == BDN_IN_BNRELU ? bn : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int npix = B * H * W;
+    const float sy = up_scale(h), sx = up_scale(w);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS;
+        hipLaunchKernelGGL(upsample2x_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)src, b, (bf16s*)out, npix, h, w, H, W, C, sy, sx); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS;
+        hipLaunchKernelGGL(upsample2x_kernel<float>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const float*)src, b, (float*)out, npix, h, w, H, W, C, sy, sx); }
+    else BDN_FAIL(BDN_E_ARG, "upsample2x: bad dtype");
+    BDN_CHECK_LAUNCH("upsample2x");
+    return BDN_OK;
+}
+
+// transpose: every source pixel gathers from the destination rows / columns that read it
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dU, int ldU, T* __restrict__ dsrc,
+                                      int npix, int h, int w, int H, int W, int C, float sy, float sx) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int top = (H - 2 * h) / 2, left = (W - 2 * w) / 2;
+    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * ITERS);
+    for (int p = blockIdx.x * rows * ITERS + row; p < p_end; p += rows) {
+        const int x = p % w, t = p / w, y = t % h, n = t / h;
+        float o[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) o[i] = 0.f;
+        const int ylo = max(0, 2 * y - 3), yhi = min(2 * h - 1, 2 * y + 5);
+        const int xlo = max(0, 2 * x - 3), xhi = min(2 * w - 1, 2 * x + 5);
+        for (int dy = ylo; dy <= yhi; dy++) {
+            int a0, a1; float ly; up_tap(dy, h, sy, a0, a1, ly);
+            const float wy = (a0 == y ? 1.f - ly : 0.f) + (a1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int dx = xlo; dx <= xhi; dx++) {
+                int b0, b1; float lx; up_tap(dx, w, sx, b0, b1, lx);
+                const float wx = (b0 == x ? 1.f - lx : 0.f) + (b1 == x ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float f[EPU];
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(dU + ((size_t)(n * H + dy + top) * W + dx + left) * ldU + c), f);
+#pragma unroll
+                for (int i = 0; i < EPU; i++) o[i] += wy * wx * f[i];
+            }
+        }
+        *reinterpret_cast<uint4*>(dsrc + (size_t)p * C + c) = Unit<T>::pack(o);
+    }
+}
+
+extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
+                                  int B, int h, int w, int H, int W, int C, void* stream) {
+    if (!dU || !dsrc) BDN_FAIL(BDN_E_ARG, "upsample2x_bwd: null pointer");
+    if (H < 2 * h || W < 2 * w || C % 16 || C > 1024 || 1024 % C || ldU < C || ldU % 16) BDN_FAIL(BDN_E_SHAPE, "upsample2x_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int npix = B * h * w;
+    const float sy = up_scale(h), sx = up_scale(w);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS;
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)dU, ldU, (bf16s*)dsrc, npix, h, w, H, W, C, sy, sx); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS;
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const float*)dU, ldU, (float*)dsrc, npix, h, w, H, W, C, sy, sx); }
+    else BDN_FAIL(BDN_E_ARG, "upsample2x_bwd: bad dtype");
+    BDN_CHECK_LAUNCH("upsample2x_bwd");
+    return BDN_OK;
+}
+
+// ============================================================ backward of product fusion + max-pool into encoder outputs
+// one loop iteration = one 2x2 window x EPU channels x both dates
+template <typename T>
+__global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
+                                    const T* __restrict__ dP, T* __restrict__ dA, int B, int H, int W, int C, int ncell) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+    float sc0[EPU], sh0[EPU], sc1[EPU], sh1[EPU];
+    load_consts<T>(bn_row(bn, 0, 2, C) + c, sc0); load_consts<T>(bn_row(bn, 0, 3, C) + c, sh0);
+    load_consts<T>(bn_row(bn, 1, 2, C) + c, sc1); load_consts<T>(bn_row(bn, 1, 3, C) + c, sh1);
+    constexpr int IT = 4;
+    const int q_end = min(ncell, (int)(blockIdx.x + 1) * rows * IT);
+    for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
+        const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
+        const bool pooled = dP != nullptr && yc < Ho && xc < Wo;   // floor-mode pooling leaves a trailing odd row/col unpooled
+        float a0[4][EPU], a1[4][EPU];                              // activations of date 1 / date 2 at the 4 window positions
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            const bool ok = y < H && x < W;
+            float f0[EPU], f1[EPU];
+            if (ok) {
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)(b * H + y) * W + x) * C + c), f0);
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)((B + b) * H + y) * W + x) * C + c), f1);
+            }
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                a0[k][i] = ok ? act1<T>(f0[i], sc0[i], sh0[i]) : 0.f;
+                a1[k][i] = ok ? act1<T>(f1[i], sc1[i], sh1[i]) : 0.f;
+            }
+        }
+        float g0[EPU], g1[EPU];
+        if (pooled) {
+            Unit<T>::unpack(*reinterpret_cast<const uint4*>(dP + ((size_t)(b * Ho + yc) * Wo + xc) * C + c), g0);
+            Unit<T>::unpack(*reinterpret_cast<const uint4*>(dP + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c), g1);
+        }
+        // route the pooled gradient to the FIRST maximum of each window (strict >, like ATen's max_pool2d)
+        float m0[EPU], m1[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            m0[i] = fmaxf(fmaxf(a0[0][i], a0[1][i]), fmaxf(a0[2][i], a0[3][i]));
+            m1[i] = fmaxf(fmaxf(a1[0][i], a1[1][i]), fmaxf(a1[2][i], a1[3][i]));
+        }
+        bool done0[EPU], done1[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) { done0[i] = !pooled; done1[i] = !pooled; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            const bool ok = y < H && x < W;
+            float df[EPU], o0[EPU], o1[EPU];
+            if (ok) Unit<T>::unpack(*reinterpret_cast<const uint4*>(dF + ((size_t)(b * H + y) * W + x) * ldF + c), df);
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                const float d = ok ? df[i] : 0.f;
+                o0[i] = d * a1[k][i];
+                o1[i] = d * a0[k][i];
+                if (!done0[i] && a0[k][i] == m0[i]) { o0[i] += g0[i]; done0[i] = true; }
+                if (!done1[i] && a1[k][i] == m1[i]) { o1[i] += g1[i]; done1[i] = true; }
+            }
+            if (ok) {
+                *reinterpret_cast<uint4*>(dA + ((size_t)(b * H + y) * W + x) * C + c) = Unit<T>::pack(o0);
+                *reinterpret_cast<uint4*>(dA + ((size_t)((B + b) * H + y) * W + x) * C + c) = Unit<T>::pack(o1);
+            }
+        }
+    }
+}
+
+extern "C" int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const float* bn,
+                                const void* dP, void* dA, int B, int H, int W, int C, void* stream) {
+    if (!dF || !z || !bn || !dA) BDN_FAIL(BDN_E_ARG, "enc_skip_bwd: null pointer");
+    if (C % 16 || C > 1024 || 1024 % C || ldF < C || ldF % 16) BDN_FAIL(BDN_E_SHAPE, "enc_skip_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
+        hipLaunchKernelGGL(enc_skip_bwd_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, B, H, W, C, ncell); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
+        hipLaunchKernelGGL(enc_skip_bwd_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, B, H, W, C, ncell); }
+    else BDN_FAIL(BDN_E_ARG, "enc_skip_bwd: bad dtype");
+    BDN_CHECK_LAUNCH("enc_skip_bwd");
+    return BDN_OK;
+}

@@ -1,0 +1,305 @@
+// Boundary kernels: NCHW<->NHWC / weight packing, the 1x1 classifier, the Tversky loss and the SGD
+// update.  All activations NHWC, 16-byte vector access
+// along channels; per-channel reductions go through per-block partials (deterministic, no atomics).
+#include "common.hpp"
+
+static inline unsigned grid_for(size_t n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// ============================================================ pack_input
+// reference boundary: BiDateNet.forward(x_d1, x_d2), models/bidate_model.py:22 (NCHW f32)
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x1, const float* __restrict__ x2, T* __restrict__ out,
+                                  int B, int C, int H, int W, int Cpad) {
+    const size_t npix = (size_t)2 * B * H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const size_t hw = (size_t)H * W;
+    const int n = i / hw; const size_t p = i % hw;
+    const float* src = (n < B ? x1 + (size_t)n * C * hw : x2 + (size_t)(n - B) * C * hw) + p;
+    T* dst = out + i * Cpad;
+    for (int c = 0; c < Cpad; c++) dst[c] = from_f<T>(c < C ? src[(size_t)c * hw] : 0.f);
+}
+
+extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,
+                              int B, int C, int H, int W, int Cpad, void* stream) {
+    if (!x_d1 || !x_d2 || !out) BDN_FAIL(BDN_E_ARG, "pack_input: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || Cpad % 16) BDN_FAIL(BDN_E_SHAPE, "pack_input: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)2 * B * H * W;
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16s>, dim3(grid_for(npix)), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad);
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, st, x_d1, x_d2, (float*)out, B, C, H, W, Cpad);
+    else BDN_FAIL(BDN_E_ARG, "pack_input: bad dtype");
+    BDN_CHECK_LAUNCH("pack_input");
+    return BDN_OK;
+}
+
+// ============================================================ pack_weights
+// wf[co][tap][ci] = w[co][ci][r][c];  wd[ci][tap][co] = w[co][ci][2-r][2-c]   (tap = 3r+c)
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                    int Cout, int Cin, int Cinp) {
+    const size_t total = (size_t)Cout * 9 * Cinp;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = i % Cinp; const size_t t = i / Cinp; const int tap = t % 9; const int co = t / 9;
+    const float v = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    if (wf) wf[i] = from_f<T>(v);
+    if (wd) wd[((size_t)ci * 9 + (8 - tap)) * Cout + co] = from_f<T>(v);
+}
+
+extern "C" int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
+                                int Cout, int Cin, int Cin_pad, void* stream) {
+    if (!w_oihw || (!wf && !wd)) BDN_FAIL(BDN_E_ARG, "pack_weights: null pointer");
+    if (Cout <= 0 || Cin <= 0 || Cin_pad < Cin) BDN_FAIL(BDN_E_SHAPE, "pack_weights: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)Cout * 9 * Cin_pad;
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16s>, dim3(grid_for(total)), dim3(256), 0, st, w_oihw, (bf16s*)wf, (bf16s*)wd, Cout, Cin, Cin_pad);
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, w_oihw, (float*)wf, (float*)wd, Cout, Cin, Cin_pad);
+    else BDN_FAIL(BDN_E_ARG, "pack_weights: bad dtype");
+    BDN_CHECK_LAUNCH("pack_weights");
+    return BDN_OK;
+}
+
+// ============================================================ outconv 1x1 (unet_parts.py:86)
+constexpr int OUTC_MAXCLS = 8;
+template <typename T>
+__global__ void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ w,
+                                const float* __restrict__ bias, float* __restrict__ logits, int B, int H, int W, int C, int ncls) {
+    constexpr int EPU = ET<T>::EPU;
+    const size_t npix = (size_t)B * H * W;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float acc[OUTC_MAXCLS];
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) acc[k] = k < ncls ? bias[k] : 0.f;
+    for (int c = 0; c < C; c += EPU) {
+        float f[EPU];
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p * C + c), f);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], bn_row(bn, 0, 2, C)[c + i], bn_row(bn, 0, 3, C)[c + i]), 0.f)));
+#pragma unroll
+            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) acc[k] = fmaf(a, w[k * C + c + i], acc[k]);
+        }
+    }
+    const size_t hw = (size_t)H * W; const size_t b = p / hw, q = p % hw;
+    for (int k = 0; k < ncls; k++) logits[(b * ncls + k) * hw + q] = acc[k];
+}
+
+extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, const float* b,
+                            float* logits, int B, int H, int W, int C, int ncls, void* stream) {
+    if (!z || !bn || !w || !b || !logits) BDN_FAIL(BDN_E_ARG, "outc_fwd: null pointer");
+    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16) BDN_FAIL(BDN_E_SHAPE, "outc_fwd: ncls=%d (max %d), C=%d", ncls, OUTC_MAXCLS, C);
+    hipStream_t st = (hipStream_t)stream; const size_t npix = (size_t)B * H * W;
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(outc_fwd_kernel<bf16s>, dim3(grid_for(npix)), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, B, H, W, C, ncls);
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(outc_fwd_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, st, (const float*)z, bn, w, b, logits, B, H, W, C, ncls);
+    else BDN_FAIL(BDN_E_ARG, "outc_fwd: bad dtype");
+    BDN_CHECK_LAUNCH("outc_fwd");
+    return BDN_OK;
+}
+
+// backward: dA[p][c] = sum_k dl[k][p] w[k][c];  dw[k][c] = sum_p dl[k][p] a[p][c];  db[k] = sum_p dl[k][p]
+// block = 256 pixels; dw/db block partials are combined with f32 atomics on a zeroed buffer (130 addresses).
+template <typename T>
+__global__ void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
+                                const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ dw, float* __restrict__ db,
+                                int B, int H, int W, int C, int ncls) {
+    constexpr int EPU = ET<T>::EPU;
+    extern __shared__ float sm[];                             // [ncls][C+1] block accumulators
+    const size_t npix = (size_t)B * H * W, hw = (size_t)H * W;
+    for (int i = threadIdx.x; i < ncls * (C + 1); i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float g[OUTC_MAXCLS];
+    const bool live = p < npix;
+    if (live) { const size_t b = p / hw, q = p % hw;
+        for (int k = 0; k < ncls; k++) g[k] = dl[(b * ncls + k) * hw + q]; }
+    else for (int k = 0; k < ncls; k++) g[k] = 0.f;
+    for (int c = 0; c < C; c += EPU) {
+        float f[EPU], o[EPU];
+        if (live) Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p * C + c), f);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            const float a = live ? to_f(from_f<T>(fmaxf(fmaf(f[i], bn_row(bn, 0, 2, C)[c + i], bn_row(bn, 0, 3, C)[c + i]), 0.f))) : 0.f;
+            float s = 0.f;
+            for (int k = 0; k < ncls; k++) {
+                s = fmaf(g[k], w[k * C + c + i], s);
+                float v = g[k] * a;                           // wave-reduce before touching LDS
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&sm[k * (C + 1) + c + i], v);
+            }
+            o[i] = s;
+        }
+        if (live) *reinterpret_cast<uint4*>(dA + p * C + c) = Unit<T>::pack(o);
+    }
+    for (int k = 0; k < ncls; k++) {
+        float v = g[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sm[k * (C + 1) + C], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncls * (C + 1); i += blockDim.x) {
+        const int k = i / (C + 1), c = i % (C + 1);
+        if (c < C) atomicAdd(&dw[k * C + c], sm[i]); else atomicAdd(&db[k], sm[i]);
+    }
+}
+
+extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
+                            void* dA, float* dw, float* db, int B, int H, int W, int C, int ncls, void* stream) {
+    if (!dlogits || !z || !bn || !w || !dA || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
+    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream; const size_t npix = (size_t)B * H * W;
+    hipMemsetAsync(dw, 0, sizeof(float) * ncls * C, st);
+    hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
+    const size_t smem = sizeof(float) * ncls * (C + 1);
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(outc_bwd_kernel<bf16s>, dim3(grid_for(npix)), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, B, H, W, C, ncls);
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(outc_bwd_kernel<float>, dim3(grid_for(npix)), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, B, H, W, C, ncls);
+    else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
+    BDN_CHECK_LAUNCH("outc_bwd");
+    return BDN_OK;
+}
+
+// ============================================================ Tversky loss (utils/metrics.py:130-171, dims == (0,2))
+// sums[k][c][w], k = 0 TP, 1 FP, 2 FN, reduced over batch and H for every (class, column w).
+// pass 1: grid (B*H rows) -> atomics on [3][ncls][W] (one add per row and address);  pass 2: single block
+// loss + coefficient tables;  pass 3: dlogits.
+__global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                    float* __restrict__ sums, int32_t* __restrict__ counts, int B, int ncls, int H, int W) {
+    // block = 256 threads = columns; grid.x = column blocks, grid.y = row groups of RG rows
+    constexpr int RG = 16;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t hw = (size_t)H * W;
+    float tp[OUTC_MAXCLS], fp[OUTC_MAXCLS], fn[OUTC_MAXCLS];
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) { tp[k] = 0.f; fp[k] = 0.f; fn[k] = 0.f; }
+    int c_tp = 0, c_fp = 0, c_fn = 0, c_ok = 0;
+    const int rows = B * H;
+    if (x < W)
+        for (int r = blockIdx.y * RG; r < min(rows, (blockIdx.y + 1) * RG); r++) {
+            const int b = r / H, y = r % H;
+            const size_t q = (size_t)y * W + x;
+            float l[OUTC_MAXCLS]; float m = -INFINITY; int am = 0;
+#pragma unroll
+            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = logits[((size_t)b * ncls + k) * hw + q]; if (l[k] > m) { m = l[k]; am = k; } }
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = expf(l[k] - m); den += l[k]; }
+            const int t = labels[(size_t)b * hw + q];
+#pragma unroll
+            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) {
+                const float p = l[k] / den;
+                if (t == k) { tp[k] += p; fn[k] += 1.f - p; } else fp[k] += p;
+            }
+            c_tp += (am == 1 && t == 1); c_fp += (am == 1 && t != 1); c_fn += (am != 1 && t == 1); c_ok += (am == t);
+        }
+    if (x < W)
+        for (int k = 0; k < ncls; k++) {
+            atomicAdd(&sums[(0 * ncls + k) * W + x], tp[k]);
+            atomicAdd(&sums[(1 * ncls + k) * W + x], fp[k]);
+            atomicAdd(&sums[(2 * ncls + k) * W + x], fn[k]);
+        }
+    if (counts) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            c_tp += __shfl_xor(c_tp, off); c_fp += __shfl_xor(c_fp, off); c_fn += __shfl_xor(c_fn, off); c_ok += __shfl_xor(c_ok, off);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], c_tp); atomicAdd(&counts[1], c_fp); atomicAdd(&counts[2], c_fn); atomicAdd(&counts[3], c_ok); }
+    }
+}
+
+// loss = 1 - mean_{c,w} TP/(TP + a FP + b FN + eps).  Overwrites sums[0] with 1/D and sums[1] with TP/D^2.
+__global__ void tversky_finish_kernel(float* __restrict__ sums, float alpha, float beta, float eps, int ncls, int W, float* __restrict__ loss) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    const int n = ncls * W;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float tp = sums[i], fp = sums[n + i], fn = sums[2 * n + i];
+        const float D = tp + alpha * fp + beta * fn + eps;
+        acc += (double)(tp / D);
+        sums[i] = 1.f / D; sums[n + i] = tp / (D * D);
+    }
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = (float)(1.0 - red[0] / n);
+}
+
+__global__ void tversky_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                   const float* __restrict__ coef, float alpha, float beta, float* __restrict__ dlogits,
+                                   int B, int ncls, int H, int W) {
+    const size_t hw = (size_t)H * W, npix = (size_t)B * hw;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const size_t b = p / hw, q = p % hw; const int x = q % W;
+    const int n = ncls * W;
+    float l[OUTC_MAXCLS], dp[OUTC_MAXCLS]; float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = logits[(b * ncls + k) * hw + q]; m = fmaxf(m, l[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = expf(l[k] - m); den += l[k]; }
+    const int t = labels[p];
+    const float norm = -1.f / (float)n;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) {
+        l[k] /= den;
+        const float invD = coef[k * W + x], tpD2 = coef[n + k * W + x];
+        const float tk = t == k ? 1.f : 0.f;
+        // d(TP/D)/dp = t/D - TP/D^2 * (t + alpha (1-t) - beta t)
+        dp[k] = norm * (tk * invD - tpD2 * (tk + alpha * (1.f - tk) - beta * tk));
+        dot += l[k] * dp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) dlogits[(b * ncls + k) * hw + q] = l[k] * (dp[k] - dot);
+}
+
+extern "C" int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
+                           float* ws, float* loss, int32_t* counts, float* dlogits,
+                           int B, int ncls, int H, int W, void* stream) {
+    if (!logits || !labels || !ws || !loss) BDN_FAIL(BDN_E_ARG, "tversky: null pointer");
+    if (ncls < 2 || ncls > OUTC_MAXCLS) BDN_FAIL(BDN_E_SHAPE, "tversky: ncls=%d unsupported (2..%d)", ncls, OUTC_MAXCLS);
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * W, st);
+    if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
+    dim3 grid((W + 255) / 256, (B * H + 15) / 16);
+    hipLaunchKernelGGL(tversky_sums_kernel, grid, dim3(256), 0, st, logits, labels, ws, counts, B, ncls, H, W);
+    BDN_CHECK_LAUNCH("tversky_sums");
+    hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(256), 0, st, ws, alpha, beta, eps, ncls, W, loss);
+    BDN_CHECK_LAUNCH("tversky_finish");
+    if (dlogits) {
+        hipLaunchKernelGGL(tversky_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, logits, labels, ws, alpha, beta, dlogits, B, ncls, H, W);
+        BDN_CHECK_LAUNCH("tversky_bwd");
+    }
+    return BDN_OK;
+}
+
+// ============================================================ SGD (train.py:55,95)
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float step, size_t n4, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        float4 a = reinterpret_cast<float4*>(p)[i]; const float4 b = reinterpret_cast<const float4*>(g)[i];
+        a.x -= step * b.x; a.y -= step * b.y; a.z -= step * b.z; a.w -= step * b.w;
+        reinterpret_cast<float4*>(p)[i] = a;
+    }
+    if (i == 0) for (size_t k = n4 * 4; k < n; k++) p[k] -= step * g[k];
+}
+
+extern "C" int bdn_sgd_step(float* params, const float* grads, float lr, float grad_scale, size_t n, void* stream) {
+    if (!params || !grads) BDN_FAIL(BDN_E_ARG, "sgd_step: null pointer");
+    if (((uintptr_t)params | (uintptr_t)grads) & 15) BDN_FAIL(BDN_E_ARG, "sgd_step: buffers must be 16-byte aligned");
+    if (n == 0) return BDN_OK;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, params, grads, lr * grad_scale, n4, n);
+    BDN_CHECK_LAUNCH("sgd_step");
+    return BDN_OK;
+}
+
+// ============================================================ misc
+static thread_local char g_err[512] = "";
+void bdn_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* bdn_last_error(void) { return g_err; }
+extern "C" int bdn_version(void) { return 1; }

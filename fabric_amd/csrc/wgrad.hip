@@ -145,17 +145,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci]
+// dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
+// One thread per (co, ci): reads are coalesced along ci, and its nine taps are 36 contiguous output bytes.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                     int S, int Cout, int Cin, int Cin_real) {
-    const size_t total = (size_t)9 * Cout * Cin;
+    const size_t plane = (size_t)Cout * Cin;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ci = i % Cin; const size_t t = i / Cin; const int co = t % Cout; const int tap = t / Cout;
+    if (i >= plane) return;
+    const int ci = i % Cin, co = i / Cin;
     if (ci >= Cin_real) return;
-    float s = 0.f;
-    for (int k = 0; k < S; k++) s += partial[(size_t)k * total + i];
-    dw[((size_t)co * Cin_real + ci) * 9 + tap] = s;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = 0.f;
+    for (int k = 0; k < S; k++) {
+        const float* p = partial + (size_t)k * 9 * plane + i;
+#pragma unroll
+        for (int t = 0; t < 9; t++) acc[t] += p[(size_t)t * plane];
+    }
+    float* o = dw + ((size_t)co * Cin_real + ci) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; t++) o[t] = acc[t];
 }
 
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; };
@@ -165,7 +174,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
     p.n_cot = Cout / 64;
     p.n_cit = (Cin + 63) / 64;
     const int tiles = p.n_cot * p.n_cit;
-    int S = (1024 + tiles - 1) / tiles;                     // aim at ~1024 blocks (4 per CU)
+    int S = (512 + tiles - 1) / tiles;                      // aim at ~512 blocks (2 per CU: 59 KB LDS each)
     if (S > p.g.n_mtiles) S = p.g.n_mtiles;
     if (S < 1) S = 1;
     p.per_split = (p.g.n_mtiles + S - 1) / S;
@@ -224,7 +233,7 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
         rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1>(a, st) : launch_wgrad<float, 8, 8, 2>(a, st);
     } else BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
     if (rc) return rc;
-    const size_t total = (size_t)9 * Cout * Cin;
+    const size_t total = (size_t)Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        partial, dw_oihw, p.S, Cout, Cin, Cin_real);
     BDN_CHECK_LAUNCH("wgrad_reduce");

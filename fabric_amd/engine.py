@@ -120,6 +120,7 @@ class Workspace:
             n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(n, hk, wk, L.cout) // 4)
             n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes(n, hk, wk, L.cout, L.cin, ipg) // 4)
         self.stats = f32(n_stats)
+        self.bnws = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device=device)
         self.n_bnb, self.n_wg = n_bnb, n_wg
         self._bwd = None
         self.logits = None
@@ -212,7 +213,7 @@ class BiDateEngine:
             call('bdn_bn_finalize', ptr(ws.stats), nt, G, L.cout, ipg * hk * wk,
                  ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']), BN_EPS, BN_MOMENTUM,
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']),
-                 ptr(P[f'{L.bn}.num_batches_tracked']), ptr(bn), st)
+                 ptr(P[f'{L.bn}.num_batches_tracked']), ptr(bn), ptr(ws.bnws), st)
         else:
             call('bdn_bn_eval', ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']),
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']), BN_EPS, G, L.cout, ptr(bn), st)

@@ -76,11 +76,13 @@ int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
  * Reduces the conv's per-tile partials and produces, per group g and channel c,
  * bn[g][0..3][c] = {mean, invstd, scale = gamma*invstd, shift = beta - mean*scale}  (layout [G][4][C]),
  * then updates running_mean/var (momentum 0.1, unbiased variance) once per group in order g=0,1,..
- * and adds G to num_batches_tracked -- the reference calls the module once per date. */
+ * and adds G to num_batches_tracked -- the reference calls the module once per date.
+ * ws: scratch of bdn_bn_finalize_workspace_bytes() (double partial sums of the two-stage reduction). */
+size_t bdn_bn_finalize_workspace_bytes(int n_mtiles, int G, int C);
 int bdn_bn_finalize(const float* stats_partial, int n_mtiles, int G, int C, int count_per_group,
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                    float* bn, void* stream);
+                    float* bn, void* ws, void* stream);
 /* Eval mode: bn[0][..] from the running buffers (mean=rm, invstd=rsqrt(rv+eps)), replicated for G groups. */
 int bdn_bn_eval(const float* gamma, const float* beta, const float* running_mean,
                 const float* running_var, float eps, int G, int C, float* bn, void* stream);

@@ -33,6 +33,7 @@ CONV_CASES = [
     (2, 5, 5, 64, 64, 0, 64, False, 2),        # odd tiny map (90-pixel patches end at 5x5)
     (1, 11, 45, 64, 64, 0, 192, True, 1),      # odd sizes, Cout not a multiple of 128
     (3, 17, 16, 128, 128, 128, 256, False, 3), # three images, two sources
+    (8, 64, 64, 64, 64, 0, 64, True, 4),       # 256 tiles: two-stage statistics reduction
 ]
 
 
@@ -76,8 +77,9 @@ def test_conv3x3_forward_stats_finalize(prec, case):
     nbt = torch.zeros(1, dtype=torch.int64, device='cuda')
     bn = torch.empty(G, 4, Cout, device='cuda')
     dg, dbeta = dev(gamma), dev(beta)
+    fws = torch.empty(_lib.load().bdn_bn_finalize_workspace_bytes(nt, G, Cout) // 8, dtype=torch.float64, device='cuda')
     _lib.call('bdn_bn_finalize', stats.data_ptr(), nt, G, Cout, ipg * H * W, dg.data_ptr(), dbeta.data_ptr(),
-              1e-5, 0.1, drm.data_ptr(), drv.data_ptr(), nbt.data_ptr(), bn.data_ptr(), st())
+              1e-5, 0.1, drm.data_ptr(), drv.data_ptr(), nbt.data_ptr(), bn.data_ptr(), fws.data_ptr(), st())
     torch.cuda.synchronize()
     bn = bn.cpu()
     rm, rv = rm0.clone(), rv0.clone()
