@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libbidate_hip.so')
+LIB_PATH = os.environ.get('BIDATE_LIB') or os.path.join(_HERE, 'csrc', 'libbidate_hip.so')
 
 BDN_F32, BDN_BF16 = 0, 1
 IN_PLAIN, IN_BNRELU = 0, 1
@@ -21,13 +21,13 @@ SIGNATURES = {
     'bdn_pack_input': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_pack_weights': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'bdn_conv3x3': (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'bdn_conv3x3_num_mtiles': (_i, [_i, _i, _i, _i]),
+    'bdn_conv3x3_num_mtiles': (_i, [_i, _i, _i, _i, _i]),
     'bdn_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_finalize_workspace_bytes': (_sz, [_i, _i, _i]),
     'bdn_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
-    'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -125,17 +125,17 @@ extern "C" int bdn_bn_eval(const float* gamma, const float* beta, const float* r
 
 // ---------------------------------------------------------------- backward (BatchNorm2d + ReLU)
 // Thread t owns channel unit t % CU and pixel lane t / CU (CU = C / EPU divides 256); a block covers
-// BNB_PIX pixels of ONE group.
-constexpr int BNB_PIX = 2048;
+// pix_per_block pixels of ONE group.
+constexpr int BNB_MAXPIX = 2048;    // upper bound of pixels per block (workspace sizing)
 
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
-                                     int pix_per_group, int blocks_per_group, int C, float* __restrict__ partial) {
+                                     int pix_per_group, int blocks_per_group, int pix_per_block, int C, float* __restrict__ partial) {
     constexpr int EPU = ET<T>::EPU;
     extern __shared__ float sred[];                           // [256][EPU][2]
     const int CU = C / EPU, rows = 256 / CU;
     const int g = blockIdx.x / blocks_per_group, bg = blockIdx.x % blocks_per_group;
-    const int p_begin = bg * BNB_PIX, p_end = min(pix_per_group, p_begin + BNB_PIX);
+    const int p_begin = bg * pix_per_block, p_end = min(pix_per_group, p_begin + pix_per_block);
     const int tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     float s0[EPU], s1[EPU], mean[EPU], inv[EPU], sc[EPU], sh[EPU];
 #pragma unroll
@@ -200,12 +200,12 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bl
 // dz = scale * (g - s0/M - xhat * s1/M)
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
-                                    const float* __restrict__ sums, int pix_per_group, int blocks_per_group, int C,
+                                    const float* __restrict__ sums, int pix_per_group, int blocks_per_group, int pix_per_block, int C,
                                     T* __restrict__ dz) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU;
     const int g = blockIdx.x / blocks_per_group, bg = blockIdx.x % blocks_per_group;
-    const int p_begin = bg * BNB_PIX, p_end = min(pix_per_group, p_begin + BNB_PIX);
+    const int p_begin = bg * pix_per_block, p_end = min(pix_per_group, p_begin + pix_per_block);
     const int tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const float invM = 1.f / (float)pix_per_group;
     float mean[EPU], inv[EPU], sc[EPU], sh[EPU], k0[EPU], k1[EPU];
@@ -231,11 +231,20 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* 
     }
 }
 
-static inline int bnb_blocks_per_group(int pix_per_group) { return (pix_per_group + BNB_PIX - 1) / BNB_PIX; }
+// pixels per block: ~1024 blocks per group for the big maps, never fewer than two pixel rows of the block
+static inline int bnb_pix_per_block(int pix_per_group, int rows) {
+    int p = (pix_per_group + 1023) / 1024;
+    if (p < 2 * rows) p = 2 * rows;
+    if (p > BNB_MAXPIX) p = BNB_MAXPIX;
+    return (p + rows - 1) / rows * rows;
+}
 
-extern "C" size_t bdn_bn_bwd_workspace_bytes(int N, int H, int W, int C) {
-    // blocks never straddle groups: bound with one group per image
-    size_t blocks = (size_t)N * bnb_blocks_per_group(H * W) + 2;
+extern "C" size_t bdn_bn_bwd_workspace_bytes(int dtype, int N, int H, int W, int C, int imgs_per_group) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || imgs_per_group <= 0 || C % 16 || C > 1024) return 0;
+    const int epu = dtype == BDN_BF16 ? 8 : 4;
+    const int ppg = imgs_per_group * H * W;
+    const int ppb = bnb_pix_per_block(ppg, 256 / (C / epu));
+    const size_t blocks = (size_t)(N / imgs_per_group) * ((ppg + ppb - 1) / ppb);
     return blocks * 2 * C * sizeof(float);
 }
 
@@ -245,14 +254,15 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
     constexpr int EPU = ET<T>::EPU;
     const int G = N / imgs_per_group;
     const int ppg = imgs_per_group * H * W;
-    const int bpg = bnb_blocks_per_group(ppg);
+    const int ppb = bnb_pix_per_block(ppg, 256 / (C / EPU));
+    const int bpg = (ppg + ppb - 1) / ppb;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(G * bpg), dim3(256), 256 * EPU * 2 * sizeof(float), st,
-                       (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, C, ws);
+                       (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, ppb, C, ws);
     BDN_CHECK_LAUNCH("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, bpg, G, C, sums, dgamma, dbeta);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
-                       (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, C, (T*)dz);
+                       (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
     BDN_CHECK_LAUNCH("bn_bwd_apply");
     return BDN_OK;
 }

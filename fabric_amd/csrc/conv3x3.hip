@@ -12,6 +12,23 @@
 // LDS, 16-byte coalesced NHWC stores.
 #include "common.hpp"
 
+// experiment switches (defaults = shipped configuration)
+#ifndef F_SCHED
+#define F_SCHED 0      // pin the W / patch global loads at the top of the tap
+#endif
+#ifndef F_FRAGDB
+#define F_FRAGDB 0     // fragment double buffer inside a tap
+#endif
+#ifndef F_PREFP
+#define F_PREFP 1      // prefetch the next chunk's patch into registers
+#endif
+#ifndef F_ROWPAD
+#define F_ROWPAD 1     // bank-conflict-free patch row pitch
+#endif
+#ifndef F_LB2
+#define F_LB2 1        // __launch_bounds__(256, 2)
+#endif
+
 struct ConvArgs {
     const void* in0; const void* in1; int C0, C1;
     const float* in_bn;          // [G][4][C0] or null
@@ -49,27 +66,41 @@ struct ConvCfg {
     static constexpr int CK = CKB / ES;
     static constexpr int UPP = CKB / 16;
     static constexpr int BM = TL::BM;
-    static constexpr int PSTR = CKB + 16;
+    static constexpr int PSTR = CKB + 16;              // LDS pixel stride: odd number of 16-byte slots
+    // LDS row pitch: a 16-lane ds_read_b128 group spans two (TW=16) or four (TW=8) patch rows; the row
+    // pitch is padded so that those rows land on disjoint bank slots (pitch/16 = 0 resp. 8 mod 16).
+    static constexpr int ROWSLOTS = TL::PW * (PSTR / 16);
+    static constexpr int RPAD = F_ROWPAD ? (((TW == 16 ? 0 : 8) - ROWSLOTS % 16 + 16) % 16) * 16 : 0;
+    static constexpr int ROWP = TL::PW * PSTR + RPAD;
     static constexpr int WSTR = CKB + 16;
     static constexpr int MI = BM / (WM * 32), NJ = BN / (WN * 32);
     static constexpr int KG = CKB / 32;
-    static constexpr int PATCH_BYTES = TL::NPIX * PSTR;
+    static constexpr int PATCH_BYTES = TI * TL::PH * ROWP;
     static constexpr int WBUF_BYTES = BN * WSTR;
     static constexpr int OSTR = BN * ES + 16;
     static constexpr int NWU = (BN * UPP + 255) / 256;
+    static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
     static constexpr int MAIN_BYTES = PATCH_BYTES + 2 * WBUF_BYTES;
     static constexpr int EPI_BYTES = BM * OSTR + WM * BN * 2 * 4;
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
+    __device__ __forceinline__ static int slot_off(int s) {       // LDS byte offset of a slot's (r=0,c=0) tap
+        int ti, py, px; TL::slot_to_nyx(s, ti, py, px);
+        return (ti * TL::PH + py) * ROWP + px * PSTR;
+    }
 };
 
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN>
+#if F_LB2
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+#else
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+#endif
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
     using TL = typename CF::TL;
-    constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, WSTR = CF::WSTR;
-    constexpr int EPU = CF::EPU, UPP = CF::UPP, NWU = CF::NWU, CK = CF::CK;
+    constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, WSTR = CF::WSTR, ROWP = CF::ROWP;
+    constexpr int EPU = CF::EPU, UPP = CF::UPP, NWU = CF::NWU, NPU = CF::NPU, CK = CF::CK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
     unsigned char* wbuf = smem + CF::PATCH_BYTES;
@@ -88,11 +119,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     // per-lane LDS offsets of the A rows (pixel slots) and B rows (output channels)
     int a_off[MI], b_off[NJ];
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-        a_off[mi] = TL::slot_to_pix((wm * MI + mi) * 32 + l31) * PSTR + half * 16;
+    for (int mi = 0; mi < MI; mi++) a_off[mi] = CF::slot_off((wm * MI + mi) * 32 + l31) + half * 16;
 #pragma unroll
-    for (int nj = 0; nj < NJ; nj++)
-        b_off[nj] = ((wn * NJ + nj) * 32 + l31) * WSTR + half * 16;
+    for (int nj = 0; nj < NJ; nj++) b_off[nj] = ((wn * NJ + nj) * 32 + l31) * WSTR + half * 16;
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -102,10 +131,44 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mi][nj][r] = 0.f;
 
-    const T* wbase = reinterpret_cast<const T*>(a.w);
-    // filter slice of one (tap, chunk): BN rows x CKB bytes, NWU 16-byte units per thread, held in registers
-    // between the global load (issued before the MFMAs of the previous tap) and the LDS store (after them).
+    // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
+    int p_pix[NPU], p_lds[NPU];                          // global pixel index (-1 = zero padding), LDS byte offset
+#pragma unroll
+    for (int i = 0; i < NPU; i++) {
+        const int u = tid + i * 256;
+        const int pix = u / UPP, sub = u % UPP;
+        const int xx = pix % TL::PW, t = pix / TL::PW, yy = t % TL::PH, ti = t / TL::PH;
+        const int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
+        const bool ok = u < TL::NPIX * UPP && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
+        p_lds[i] = u < TL::NPIX * UPP ? (ti * TL::PH + yy) * ROWP + xx * PSTR + sub * 16 : -1;
+    }
+    const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
+    uint4 preg[NPU];
+#define LOAD_PATCH(c0_)                                                                                  \
+    {                                                                                                   \
+        const T* src_; int cs_, Cs_;                                                                    \
+        if ((c0_) < a.C0) { src_ = reinterpret_cast<const T*>(a.in0); Cs_ = a.C0; cs_ = (c0_); }        \
+        else { src_ = reinterpret_cast<const T*>(a.in1); Cs_ = a.C1; cs_ = (c0_) - a.C0; }              \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
+            if (p_pix[i] >= 0) preg[i] = *reinterpret_cast<const uint4*>(src_ + (size_t)p_pix[i] * Cs_ + cs_ + p_sub); \
+    }
+#define STORE_PATCH(c0_)                                                                                 \
+    {                                                                                                   \
+        const bool bn_ = a.in_bn != nullptr && (c0_) < a.C0;                                            \
+        const float* sc_ = bn_ ? bn_row(a.in_bn, grp, 2, a.C0) + (c0_) + p_sub : nullptr;               \
+        const float* sh_ = bn_ ? bn_row(a.in_bn, grp, 3, a.C0) + (c0_) + p_sub : nullptr;               \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
+            if (p_lds[i] >= 0) {                                                                        \
+                uint4 v_ = make_uint4(0, 0, 0, 0);                                                      \
+                if (p_pix[i] >= 0) v_ = bn_ ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];              \
+                *reinterpret_cast<uint4*>(patch + p_lds[i]) = v_;                                       \
+            }                                                                                           \
+    }
+
+    // ---- filter slice of one (tap, chunk): BN rows x CKB bytes, NWU units per thread, global -> regs -> LDS.
     // Plain unrolled code on purpose: a lambda capturing the register array by reference sent it to scratch.
+    const T* wbase = reinterpret_cast<const T*>(a.w);
     constexpr bool W_EXACT = (BN * UPP) % 256 == 0;
     uint4 wreg[NWU];
     const T* wsrc[NWU];
@@ -126,26 +189,45 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         if (W_EXACT || tid + i * 256 < BN * UPP)                                                        \
             *reinterpret_cast<uint4*>(wbuf + (buf_) * CF::WBUF_BYTES + wdst[i]) = wreg[i];
 
+    LOAD_PATCH(0)
     for (int c0 = 0; c0 < Cin; c0 += CK) {
-        // ---- stage the activation patch of this channel chunk (LDS free: previous chunk ended with a barrier)
-        {
-            const T* src; int Csrc, cs; const float *sc = nullptr, *sh = nullptr;
-            if (c0 < a.C0) {
-                src = reinterpret_cast<const T*>(a.in0); Csrc = a.C0; cs = c0;
-                if (a.in_bn) { sc = bn_row(a.in_bn, grp, 2, a.C0) + c0; sh = bn_row(a.in_bn, grp, 3, a.C0) + c0; }
-            } else {
-                src = reinterpret_cast<const T*>(a.in1); Csrc = a.C1; cs = c0 - a.C0;
-            }
-            stage_patch<T, CKB, PSTR, TH, TW, TI>(patch, src, Csrc, cs, CK, sc, sh, n0, y0, x0, a.N, a.H, a.W, tid);
-        }
+        // LDS is free here: the previous chunk ended with a barrier
+        if (!F_PREFP && c0 > 0) { LOAD_PATCH(c0) }
+        STORE_PATCH(c0)
         LOAD_W(0, c0)
         STORE_W(0)
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            if (tap < 8) { LOAD_W(tap + 1, c0) }                 // global -> regs, in flight during the MFMAs
+            // issue the global loads FIRST and pin them there (left alone, the scheduler sinks them below the
+            // MFMAs, right in front of their LDS store, which exposes the full L2 latency every tap)
+            if (tap < 8) { LOAD_W(tap + 1, c0) }
+            if (F_PREFP && tap == 5 && c0 + CK < Cin) { LOAD_PATCH(c0 + CK) }   // next chunk's activations: 3 taps of cover
+#if F_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const unsigned char* wb = wbuf + (tap & 1) * CF::WBUF_BYTES;
-            const int tapoff = ((tap / 3) * TL::PW + (tap % 3)) * PSTR;
+            const int tapoff = (tap / 3) * ROWP + (tap % 3) * PSTR;
+#if F_FRAGDB
+            uint4 fa[2][MI], fb[2][NJ];                  // fragment double buffer: reads of k-group g+1 fly under MFMAs of g
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) fa[0][mi] = *reinterpret_cast<const uint4*>(patch + a_off[mi] + tapoff);
+#pragma unroll
+            for (int nj = 0; nj < NJ; nj++) fb[0][nj] = *reinterpret_cast<const uint4*>(wb + b_off[nj]);
+#pragma unroll
+            for (int kg = 0; kg < KG; kg++) {
+                if (kg + 1 < KG) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) fa[(kg + 1) & 1][mi] = *reinterpret_cast<const uint4*>(patch + a_off[mi] + tapoff + (kg + 1) * 32);
+#pragma unroll
+                    for (int nj = 0; nj < NJ; nj++) fb[(kg + 1) & 1][nj] = *reinterpret_cast<const uint4*>(wb + b_off[nj] + (kg + 1) * 32);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; nj++) Mma<T>::run(fa[kg & 1][mi], fb[kg & 1][nj], acc[mi][nj]);
+            }
+#else
 #pragma unroll
             for (int kg = 0; kg < KG; kg++) {
                 uint4 af[MI], bf[NJ];
@@ -158,12 +240,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                     for (int nj = 0; nj < NJ; nj++) Mma<T>::run(af[mi], bf[nj], acc[mi][nj]);
             }
+#endif
             if (tap < 8) { STORE_W((tap + 1) & 1) }              // other buffer: last read before the previous barrier
             __syncthreads();
         }
     }
 #undef LOAD_W
 #undef STORE_W
+#undef LOAD_PATCH
+#undef STORE_PATCH
 
     // ------------------------------------------------------------------ epilogue (LDS reused)
     unsigned char* otile = smem;
@@ -229,20 +314,41 @@ static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     return BDN_OK;
 }
 
+// Tile choice (shared with bdn_conv3x3_num_mtiles so the caller can size the statistics buffer):
+//   8x8x2 images   for maps up to 8x8;
+//   16x16 (BM=256) for 64-wide outputs on larger maps: one filter slice feeds twice the pixels;
+//   8x16  (BM=128) otherwise.  BN = 128 when Cout allows it and the grid still has >= 512 blocks.
+struct ConvPlan { TileGeom g; int BN; };
+static ConvPlan conv_plan(int N, int H, int W, int Cout, int imgs_per_group) {
+    ConvPlan p;
+    TileGeom& g = p.g;
+    const bool narrow = (Cout % 128 != 0);
+    if (W <= 8 && H <= 8 && imgs_per_group % 2 == 0) { g.TI = 2; g.TH = 8; g.TW = 8; }
+    else if (narrow && H >= 12 && W >= 12) { g.TI = 1; g.TH = 16; g.TW = 16; }
+    else { g.TI = 1; g.TH = 8; g.TW = 16; }
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    g.n_mtiles = ((N + g.TI - 1) / g.TI) * g.tiles_y * g.tiles_x;
+    p.BN = (!narrow && (long)g.n_mtiles * (Cout / 128) >= 512) ? 128 : 64;
+    if (g.TH == 16) p.BN = 64;
+    return p;
+}
+
 template <typename T, int CKB>
-static int dispatch_conv(const ConvArgs& a, const TileGeom& g, hipStream_t st) {
-    const bool wide = (a.Cout % 128 == 0);
+static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+    const TileGeom& g = p.g;
+    if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
     if (g.TI == 1) {
-        if (wide) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
+        if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
         return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
     }
-    if (wide) return launch_conv<T, CKB, 8, 8, 2, 128, 2, 2>(a, g.n_mtiles, st);
+    if (p.BN == 128) return launch_conv<T, CKB, 8, 8, 2, 128, 2, 2>(a, g.n_mtiles, st);
     return launch_conv<T, CKB, 8, 8, 2, 64, 2, 2>(a, g.n_mtiles, st);
 }
 
-extern "C" int bdn_conv3x3_num_mtiles(int N, int H, int W, int imgs_per_group) {
-    if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0) return 0;
-    return pick_tile(N, H, W, imgs_per_group).n_mtiles;
+extern "C" int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || imgs_per_group <= 0) return 0;
+    return conv_plan(N, H, W, Cout, imgs_per_group).g.n_mtiles;
 }
 
 extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
@@ -263,8 +369,8 @@ extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, 
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
-    TileGeom g = pick_tile(N, H, W, imgs_per_group);
-    a.tiles_y = g.tiles_y; a.tiles_x = g.tiles_x; a.n_ntiles = 0;
+    const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
+    a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Cin = C0 + C1;
     if (dtype == BDN_BF16) {

@@ -116,8 +116,8 @@ class Workspace:
         for L in eng.layers:
             hk, wk = self.dims[L.level - 1]
             n, ipg = (2 * B, B) if L.enc else (B, B)
-            n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, ipg) * 2 * L.cout)
-            n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(n, hk, wk, L.cout) // 4)
+            n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg) * 2 * L.cout)
+            n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(eng.dt, n, hk, wk, L.cout, ipg) // 4)
             n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes(n, hk, wk, L.cout, L.cin, ipg) // 4)
         self.stats = f32(n_stats)
         self.bnws = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device=device)
@@ -157,13 +157,21 @@ class BiDateEngine:
     # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
     def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg):
         """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to (csrc/conv3x3.hip)."""
-        ti, th, tw = (2, 8, 8) if (w <= 8 and h <= 8 and ipg % 2 == 0) else (1, 8, 16)
-        bn = 128 if cout % 128 == 0 else 64
+        narrow = cout % 128 != 0
+        if w <= 8 and h <= 8 and ipg % 2 == 0:
+            ti, th, tw = 2, 8, 8
+        elif narrow and h >= 12 and w >= 12:
+            ti, th, tw = 1, 16, 16
+        else:
+            ti, th, tw = 1, 8, 16
+        n_mt = -(-n // ti) * -(-h // th) * -(-w // tw)
+        bn = 128 if (not narrow and n_mt * (cout // 128) >= 512) else 64
+        wmn = '4,1' if th == 16 else '2,2'
         if self.precision == 'bf16':
             t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
         else:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
-        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},2,2>'
+        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn}>'
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args):
         if self.prof is None:
@@ -209,7 +217,7 @@ class BiDateEngine:
         bn = ws.bn[L.name]
         G = n // ipg
         if training:
-            nt = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, ipg)
+            nt = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg)
             call('bdn_bn_finalize', ptr(ws.stats), nt, G, L.cout, ipg * hk * wk,
                  ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']), BN_EPS, BN_MOMENTUM,
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']),

@@ -60,7 +60,7 @@ int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 int in_mode, const float* in_bn, int imgs_per_group,
                 const void* w, const float* bias, void* out, float* stats_partial,
                 int N, int H, int W, int Cout, void* stream);
-int bdn_conv3x3_num_mtiles(int N, int H, int W, int imgs_per_group);
+int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group);
 
 /* ---- weight gradient of the same convolution (autograd of models/unet_parts.py:13,16) ----
  * dz: [N,H,W,Cout]; inputs as in bdn_conv3x3.  partial: workspace of bdn_wgrad_workspace_bytes().
@@ -92,7 +92,7 @@ int bdn_bn_eval(const float* gamma, const float* beta, const float* running_mean
  * dgamma/dbeta (accumulated over groups, overwritten) ; dz = scale*(g - s0/M - xhat*s1/M).
  * dA: [N,H,W,ldA] channel slice starting at dA pointer (ldA = channel stride of the dA tensor).
  * ws: workspace of bdn_bn_bwd_workspace_bytes(). */
-size_t bdn_bn_bwd_workspace_bytes(int N, int H, int W, int C);
+size_t bdn_bn_bwd_workspace_bytes(int dtype, int N, int H, int W, int C, int imgs_per_group);
 int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* bn,
                int imgs_per_group, int N, int H, int W, int C,
                float* ws, float* sums, float* dgamma, float* dbeta, void* dz, void* stream);

@@ -61,7 +61,7 @@ def test_conv3x3_forward_stats_finalize(prec, case):
     wf, _ = pack_w(prec, wp, C0 + C1)
     d0, d1 = to_nhwc(prec, x0), (to_nhwc(prec, x1) if C1 else None)
     out = torch.empty(N, H, W, Cout, dtype=td, device='cuda')
-    nt = _lib.load().bdn_conv3x3_num_mtiles(N, H, W, ipg)
+    nt = _lib.load().bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
     stats = torch.full((nt, 2, Cout), float('nan'), device='cuda')
     dbn = dev(bn_in) if bnrelu else None
     db = dev(b)
@@ -201,7 +201,7 @@ def test_bn_bwd(prec, case):
     dz_d = torch.empty(N, H, W, C, dtype=td, device='cuda')
     dA_d = to_nhwc(prec, dA_full)
     z_d = to_nhwc(prec, z)
-    wsb = torch.empty(_lib.load().bdn_bn_bwd_workspace_bytes(N, H, W, C) // 4, device='cuda')
+    wsb = torch.empty(_lib.load().bdn_bn_bwd_workspace_bytes(dt, N, H, W, C, ipg) // 4, device='cuda')
     sums = torch.empty(G, 2, C, device='cuda')
     dgam, dbet = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
     bn_d = dev(bn)
