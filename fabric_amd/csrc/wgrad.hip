@@ -45,17 +45,22 @@ __device__ __forceinline__ uint4 tr_pair(const unsigned char* p0, const unsigned
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-template <typename T, int TH, int TW, int TI>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+// KSPLIT: for inputs with <= 32 channels the second half of the 64-wide ci tile is empty; the two waves
+// that would own it take every other 16-pixel k-step instead and write their own partial slice.
+template <typename T, int TH, int TW, int TI, bool KSPLIT>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     using CF = WgCfg<T, TH, TW, TI>;
     using TL = typename CF::TL;
     constexpr int STR = CF::STR, EPU = ET<T>::EPU, UPP = CF::CKB / 16;
+    constexpr int NPU = (TL::NPIX * UPP + 255) / 256, NDU = TL::BM * UPP / 256;
+    static_assert((TL::BM * UPP) % 256 == 0 && 256 % UPP == 0, "unit ownership");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
     unsigned char* dzt = smem + CF::PATCH_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;             // wave tile: co [wm*32,+32) x ci [wn*32,+32)
+    const int wm = wave >> 1, wn = KSPLIT ? 0 : (wave & 1);   // wave tile: co [wm*32,+32) x ci [wn*32,+32)
+    const int kpar = KSPLIT ? (wave & 1) : 0;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -69,6 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     else { src = reinterpret_cast<const T*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
     const int cvalid = min(64, Csrc - cs);
     const T* dzp = reinterpret_cast<const T*>(a.dz);
+    const int sub_e = (tid % UPP) * EPU;                      // channel offset of this thread's units
+    const bool sub_ok = sub_e < cvalid;
 
     f32x16 acc[9];
 #pragma unroll
@@ -76,26 +83,59 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
+    // per-thread staging registers: next chunk's activation-patch units and dz units travel global -> regs while
+    // the current chunk is in the MFMAs, regs -> LDS after the barrier
+    uint4 preg[NPU], dreg[NDU];
+    unsigned p_ok = 0;                                       // bit i: patch unit i lies inside the image
+    int grp_next = 0;
+#define LOAD_CHUNK(q_)                                                                                   \
+    {                                                                                                   \
+        const int tx_ = (q_) % a.tiles_x, ty_ = ((q_) / a.tiles_x) % a.tiles_y, ib_ = (q_) / (a.tiles_x * a.tiles_y); \
+        const int n0_ = ib_ * TI, y0_ = ty_ * TH, x0_ = tx_ * TW;                                       \
+        grp_next = n0_ / a.imgs_per_group; p_ok = 0;                                                    \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
+            const int u = tid + i * 256, pix = u / UPP;                                                  \
+            const int xx = pix % TL::PW, t_ = pix / TL::PW, yy = t_ % TL::PH, ti = t_ / TL::PH;          \
+            const int n = n0_ + ti, y = y0_ + yy - 1, x = x0_ + xx - 1;                                  \
+            const bool ok_ = u < TL::NPIX * UPP && sub_ok && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
+            p_ok |= (ok_ ? 1u : 0u) << i;                                                                \
+            if (ok_) preg[i] = *reinterpret_cast<const uint4*>(src + ((size_t)(n * a.H + y) * a.W + x) * Csrc + cs + sub_e); \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < NDU; i++) {                                                \
+            const int slot = (tid + i * 256) / UPP;                                                      \
+            int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);                                           \
+            const int n = n0_ + ti, y = y0_ + py, x = x0_ + px;                                          \
+            dreg[i] = make_uint4(0, 0, 0, 0);                                                            \
+            if (n < a.N && y < a.H && x < a.W)                                                           \
+                dreg[i] = *reinterpret_cast<const uint4*>(dzp + ((size_t)(n * a.H + y) * a.W + x) * a.Cout + co0 + sub_e); \
+        }                                                                                               \
+    }
+#define STORE_CHUNK()                                                                                    \
+    {                                                                                                   \
+        const float* sc_ = use_bn ? bn_row(a.in_bn, grp_next, 2, a.C0) + cs + sub_e : nullptr;          \
+        const float* sh_ = use_bn ? bn_row(a.in_bn, grp_next, 3, a.C0) + cs + sub_e : nullptr;          \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
+            const int u = tid + i * 256;                                                                 \
+            if (u < TL::NPIX * UPP) {                                                                    \
+                uint4 v_ = make_uint4(0, 0, 0, 0);                                                       \
+                if ((p_ok >> i) & 1u) v_ = use_bn ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];                  \
+                *reinterpret_cast<uint4*>(patch + (u / UPP) * STR + (u % UPP) * 16) = v_;                \
+            }                                                                                           \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < NDU; i++) {                                                \
+            const int u = tid + i * 256;                                                                 \
+            *reinterpret_cast<uint4*>(dzt + (u / UPP) * STR + (u % UPP) * 16) = dreg[i];                 \
+        }                                                                                               \
+    }
+
     const int q_begin = split * a.per_split;
     const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    if (q_begin < q_end) LOAD_CHUNK(q_begin)
     for (int q = q_begin; q < q_end; q++) {
-        const int tx = q % a.tiles_x, ty = (q / a.tiles_x) % a.tiles_y, ib = q / (a.tiles_x * a.tiles_y);
-        const int n0 = ib * TI, y0 = ty * TH, x0 = tx * TW;
-        const int grp = n0 / a.imgs_per_group;
-        const float* sc = use_bn ? bn_row(a.in_bn, grp, 2, a.C0) + cs : nullptr;
-        const float* sh = use_bn ? bn_row(a.in_bn, grp, 3, a.C0) + cs : nullptr;
-        __syncthreads();                                   // previous chunk's reads are done
-        stage_patch<T, CF::CKB, STR, TH, TW, TI>(patch, src, Csrc, cs, cvalid, sc, sh, n0, y0, x0, a.N, a.H, a.W, tid);
-        for (int u = tid; u < TL::BM * UPP; u += 256) {   // dz tile, zero for slots outside the image
-            const int slot = u / UPP, sub = u % UPP;
-            int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
-            const int n = n0 + ti, y = y0 + py, x = x0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < a.N && y < a.H && x < a.W)
-                v = *reinterpret_cast<const uint4*>(dzp + ((size_t)(n * a.H + y) * a.W + x) * a.Cout + co0 + sub * EPU);
-            *reinterpret_cast<uint4*>(dzt + slot * STR + sub * 16) = v;
-        }
+        __syncthreads();                                   // previous chunk's LDS reads are done
+        STORE_CHUNK()
         __syncthreads();
+        if (q + 1 < q_end) LOAD_CHUNK(q + 1)
 
         if constexpr (sizeof(T) == 2) {
             // lane's transposing-read role: pixel (lane&15)>>2 of a 4-pixel group, 4-channel piece (lane&3)
@@ -103,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
             const int kpix = (lane & 15) >> 2;
 #pragma unroll 2
-            for (int ks = 0; ks < TL::BM / 16; ks++) {
+            for (int ks = kpar; ks < TL::BM / 16; ks += KSPLIT ? 2 : 1) {
                 const int s0 = ks * 16 + half * 8 + kpix;            // k = 8*half + [0,4) ; +4 for the second read
                 const uint4 af = tr_pair(dzt + s0 * STR + wm * 64 + chan_b, dzt + (s0 + 4) * STR + wm * 64 + chan_b);
                 const unsigned char* pb0 = patch + TL::slot_to_pix(s0) * STR + wn * 64 + chan_b;
@@ -118,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             }
         } else {
 #pragma unroll 2
-            for (int ks = 0; ks < TL::BM / 2; ks++) {
+            for (int ks = kpar; ks < TL::BM / 2; ks += KSPLIT ? 2 : 1) {
                 const int s = ks * 2 + half;
                 const float av = *reinterpret_cast<const float*>(dzt + s * STR + (wm * 32 + l31) * 4);
                 const unsigned char* pb = patch + TL::slot_to_pix(s) * STR + (wn * 32 + l31) * 4;
@@ -131,43 +171,76 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             }
         }
     }
+#undef LOAD_CHUNK
+#undef STORE_CHUNK
 
-    // partial[split][tap][co][ci]
+    // partial[psplit][tap][co][ci]
     const int ci = ci0 + wn * 32 + l31;
+    const int psplit = KSPLIT ? split * 2 + kpar : split;
     if (ci < Cin) {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                a.partial[(((size_t)split * 9 + tap) * a.Cout + co) * Cin + ci] = acc[tap][r];
+                a.partial[(((size_t)psplit * 9 + tap) * a.Cout + co) * Cin + ci] = acc[tap][r];
             }
     }
 }
 
 // dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
-// One thread per (co, ci): reads are coalesced along ci, and its nine taps are 36 contiguous output bytes.
+// Block = SL split lanes x (256/SL) (co,ci) pairs: reads are coalesced along ci, the SL lanes walk the
+// splits in parallel (fixed order -> deterministic), an LDS tree combines them, and each pair's nine taps
+// leave as 36 contiguous bytes of the reference's OIHW layout.
+template <int SL>
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                     int S, int Cout, int Cin, int Cin_real) {
+    constexpr int PAIRS = 256 / SL;
+    __shared__ float sm[SL][PAIRS][9];
     const size_t plane = (size_t)Cout * Cin;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= plane) return;
-    const int ci = i % Cin, co = i / Cin;
-    if (ci >= Cin_real) return;
+    const int pl = threadIdx.x % PAIRS, sl = threadIdx.x / PAIRS;
+    const size_t i = (size_t)blockIdx.x * PAIRS + pl;
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = 0.f;
-    for (int k = 0; k < S; k++) {
-        const float* p = partial + (size_t)k * 9 * plane + i;
+    if (i < plane)
+        for (int k = sl; k < S; k += SL) {
+            const float* p = partial + (size_t)k * 9 * plane + i;
 #pragma unroll
-        for (int t = 0; t < 9; t++) acc[t] += p[(size_t)t * plane];
+            for (int t = 0; t < 9; t++) acc[t] += p[(size_t)t * plane];
+        }
+#pragma unroll
+    for (int t = 0; t < 9; t++) sm[sl][pl][t] = acc[t];
+    __syncthreads();
+    if (sl == 0 && i < plane) {
+        const int ci = i % Cin, co = i / Cin;
+        if (ci < Cin_real) {
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                float v = acc[t];
+                for (int k = 1; k < SL; k++) v += sm[k][pl][t];
+                dw[((size_t)co * Cin_real + ci) * 9 + t] = v;
+            }
+        }
     }
-    float* o = dw + ((size_t)co * Cin_real + ci) * 9;
-#pragma unroll
-    for (int t = 0; t < 9; t++) o[t] = acc[t];
 }
 
-struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; };
+static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout, int Cin, int Cin_real, hipStream_t st) {
+    const size_t plane = (size_t)Cout * Cin;
+    // enough split lanes to give the small filters some parallelism, never more lanes than splits
+    int SL = 1;
+    while (SL < 16 && SL * 2 <= S && plane / (256 / (SL * 2)) < 2048) SL *= 2;
+    const unsigned grid = (unsigned)((plane + 256 / SL - 1) / (256 / SL));
+    switch (SL) {
+        case 1: hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
+        case 2: hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
+        case 4: hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
+        case 8: hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
+        default: hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
+    }
+}
+
+struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; };
 static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
     WgPlan p;
     p.g = pick_tile(N, H, W, imgs_per_group);
@@ -179,19 +252,20 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
     if (S < 1) S = 1;
     p.per_split = (p.g.n_mtiles + S - 1) / S;
     p.S = (p.g.n_mtiles + p.per_split - 1) / p.per_split;   // no empty splits
+    p.ksplit = Cin <= 32;
     return p;
 }
 
 extern "C" size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || imgs_per_group <= 0) return 0;
     WgPlan p = wgrad_plan(N, H, W, Cout, Cin, imgs_per_group);
-    return (size_t)p.S * 9 * Cout * Cin * sizeof(float);
+    return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * Cin * sizeof(float);
 }
 
-template <typename T, int TH, int TW, int TI>
+template <typename T, int TH, int TW, int TI, bool KSPLIT>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     using CF = WgCfg<T, TH, TW, TI>;
-    auto kern = wgrad_kernel<T, TH, TW, TI>;
+    auto kern = wgrad_kernel<T, TH, TW, TI, KSPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
@@ -228,14 +302,14 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (dtype == BDN_BF16) {
-        rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1>(a, st) : launch_wgrad<bf16s, 8, 8, 2>(a, st);
+        if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
+        else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);
     } else if (dtype == BDN_F32) {
-        rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1>(a, st) : launch_wgrad<float, 8, 8, 2>(a, st);
+        if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1, true>(a, st) : launch_wgrad<float, 8, 8, 2, true>(a, st);
+        else rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1, false>(a, st) : launch_wgrad<float, 8, 8, 2, false>(a, st);
     } else BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
     if (rc) return rc;
-    const size_t total = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       partial, dw_oihw, p.S, Cout, Cin, Cin_real);
+    launch_wgrad_reduce(partial, dw_oihw, p.S * (p.ksplit ? 2 : 1), Cout, Cin, Cin_real, st);
     BDN_CHECK_LAUNCH("wgrad_reduce");
     return BDN_OK;
 }
