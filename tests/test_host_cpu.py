@@ -1,0 +1,145 @@
+"""CPU tests of the host side: C-ABI surface, module / state-dict schema, dataset API, DDP bucketer."""
+import ctypes
+import os
+import random
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/bidate_hip.h <-> libbidate_hip.so <-> fabric_amd/_lib.py agree (no compute call: no GPU here)."""
+    from fabric_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'bidate_hip.h')).read()
+    declared = set(re.findall(r'\b(bdn_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in the header but not exported'
+    assert _lib.load().bdn_version() >= 1
+    assert isinstance(_lib.load().bdn_last_error(), bytes)
+
+
+def test_argument_validation_needs_no_gpu():
+    from fabric_amd import _lib
+    lib = _lib.load()
+    assert lib.bdn_conv3x3_num_mtiles(128, 128, 128, 64, 64) == 128 * 8 * 8      # 16x16 tiles for 64-wide outputs
+    assert lib.bdn_conv3x3_num_mtiles(128, 128, 128, 128, 64) == 128 * 16 * 8    # 8x16 tiles
+    assert lib.bdn_conv3x3_num_mtiles(128, 8, 8, 512, 64) == 64                   # two 8x8 images per tile
+    assert lib.bdn_wgrad_workspace_bytes(2, 16, 16, 64, 64, 1) > 0
+    with pytest.raises(RuntimeError, match='null pointer'):
+        _lib.call('bdn_conv3x3', 1, None, 64, None, 0, 0, None, 1, None, None, None, None, 1, 8, 8, 64, None)
+    with pytest.raises(RuntimeError, match='multiple of 64'):
+        _lib.call('bdn_conv3x3', 1, 1, 64, None, 0, 0, None, 1, 1, None, 1, None, 1, 8, 8, 65, None)
+
+
+def test_state_dict_schema_matches_reference():
+    """128 entries, reference key names and shapes."""
+    from fabric_amd import BiDateNet
+    from fabric_amd.engine import param_order
+    from oracle.bidate_oracle import build_torch_baseline
+    m = BiDateNet(13, 2)
+    sd = m.state_dict()
+    ref = build_torch_baseline(13, 2).state_dict()
+    assert len(sd) == 128 and list(sd) == list(ref)
+    assert all(sd[k].shape == ref[k].shape and sd[k].dtype == ref[k].dtype for k in sd)
+    assert sum(p.numel() for p in m.parameters()) == 13401154
+    assert sd['inc.conv.conv.0.weight'].shape == (64, 13, 3, 3)
+    assert sd['up1.conv.conv.0.weight'].shape == (256, 1024, 3, 3)
+    order = param_order(13)
+    assert set(order) == {k for k, _ in m.named_parameters()} and len(order) == 74
+    # a DataParallel-style checkpoint ('module.' prefix, reference train.py:222) loads after stripping the prefix
+    m.load_state_dict({k[len('module.'):]: v for k, v in {('module.' + k): v for k, v in ref.items()}.items()})
+
+
+def test_modules_refuse_cpu_and_have_no_fallback():
+    from fabric_amd import BiDateNet
+    from fabric_amd.models import unet_parts
+    m = BiDateNet(3, 2)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match='fused HIP stages'):
+        unet_parts.double_conv(3, 64)(torch.zeros(1, 3, 8, 8))
+    src = open(os.path.join(ROOT, 'fabric_amd', 'engine.py')).read() + open(os.path.join(ROOT, 'fabric_amd', '_lib.py')).read()
+    assert 'oracle' not in src, 'the product must never import the oracle'
+
+
+def test_patch_pair_dataset_matches_reference_fixture(golden_dir):
+    """G7: OneraPreloader / onera_siamese_loader on a fixed random.seed reproduce the reference's outputs."""
+    from fabric_amd.utils.dataloaders import OneraPreloader
+    g = np.load(os.path.join(golden_dir, 'g7_loader.npz'))
+    r = np.random.default_rng(7)
+    data = {'cityA': {'images': r.standard_normal((2, 3, 40, 36)).astype(np.float32),
+                      'labels': (r.uniform(0, 1, (40, 36)) < 0.2).astype(np.uint8)},
+            'cityB': {'images': r.standard_normal((2, 3, 30, 50)).astype(np.float32),
+                      'labels': (r.uniform(0, 1, (30, 50)) < 0.2).astype(np.uint8)}}
+    meta = [['cityA', 0, 0], ['cityA', 16, 8], ['cityB', 4, 30], ['cityB', 10, 0], ['cityA', 20, 20]]
+    random.seed(1234)
+    ds = OneraPreloader('unused/', meta, data, 12, aug=True)
+    assert np.array_equal(np.array([[m[1], m[2], 0 if m[0] == 'cityA' else 1] for m in ds.imgs]), g['order'])
+    for i in range(len(ds)):
+        a, b, l = ds[i]
+        assert a.dtype == np.float32 and l.dtype == np.uint8 and a.shape == (3, 12, 12) and l.shape == (12, 12)
+        assert np.array_equal(a, g[f'img1_{i}']) and np.array_equal(b, g[f'img2_{i}']) and np.array_equal(l, g[f'lbl_{i}'])
+
+
+def test_patch_origin_rule():
+    from fabric_amd.utils.dataloaders import metadata_from_shapes, patch_origins
+    assert patch_origins(300, 260, 90, 180) == [[0, 0], [180, 0]]     # metadata.json defaults; j=180 does not fit in 260
+    tr, va = metadata_from_shapes({'a': (100, 100), 'b': (200, 95)}, ['b'], 90, 90)
+    assert tr == [['a', 0, 0]] and va == [['b', 0, 0], ['b', 90, 0]]
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from fabric_amd.parallel import FlatLayout, GradBucketer, shard_indices
+from fabric_amd.engine import param_order
+from fabric_amd import BiDateNet
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[4]
+dist.init_process_group('gloo', rank=rank, world_size=world)
+m = BiDateNet(3, 2)
+order = param_order(3)
+lay = FlatLayout([(k, p.shape) for k, p in m.named_parameters()], order)
+flat = torch.zeros(lay.total)
+tail = [k for k in order if k.endswith('.bias') and k.split('.')[-2] in ('0', '3')]
+b = GradBucketer(lay, flat, n_buckets=4, keys_no_reduce=tail)
+assert len(b.buckets) == 4 and b.buckets[0][0] == 0 and b.buckets[-1][1] == b.reduce_end
+for step in range(2):
+    for k in order:                       # "backward": gradients appear in layout order
+        g = lay.view(flat, k)
+        g.fill_(0.0 if k in tail else float(rank + 1) * (1 + step))
+        b.on_ready([k])
+    b.finish()
+    expect = sum(r + 1 for r in range(world)) * (1 + step)
+    for k in order:
+        v = lay.view(flat, k)
+        assert torch.all(v == (0.0 if k in tail else expect)), (k, v.flatten()[0].item(), expect)
+idx = [shard_indices(103, r, world) for r in range(world)]
+assert all(len(i) == 103 // world for i in idx) and len(set(sum(idx, []))) == (103 // world) * world
+dist.barrier(); dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_grad_bucketer_gloo_world2(tmp_path):
+    """N>1 path on CPU: two gloo ranks, bucketed async all-reduce over the flat gradient buffer."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', ROOT, port],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+    assert all('ok' in o for o in outs)
