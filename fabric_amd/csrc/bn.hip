@@ -166,35 +166,25 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dA, int ldA, const T*
     }
 }
 
-// reduce the per-block partials -> sums[g][2][C]; dgamma / dbeta are summed over groups
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks_per_group, int G, int C,
+// second stage of the two-stage row reduction: part2[g][s][2][C] (double) -> sums[g][2][C]; dgamma / dbeta are
+// summed over groups
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part2, int RS, int G, int C,
                                        float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sm[16][16][2];
-    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
     double t0 = 0.0, t1 = 0.0;
     for (int g = 0; g < G; g++) {
         double a0 = 0.0, a1 = 0.0;
-        if (c < C)
-            for (int r = rl; r < blocks_per_group; r += 16) {
-                const size_t row = (size_t)g * blocks_per_group + r;
-                a0 += partial[(row * 2 + 0) * C + c];
-                a1 += partial[(row * 2 + 1) * C + c];
-            }
-        sm[rl][cl][0] = a0; sm[rl][cl][1] = a1;
-        __syncthreads();
-        if (rl == 0 && c < C) {
-            for (int r = 1; r < 16; r++) { a0 += sm[r][cl][0]; a1 += sm[r][cl][1]; }
-            sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
-            sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
-            t0 += a0; t1 += a1;
+        for (int s = 0; s < RS; s++) {
+            a0 += part2[(((size_t)g * RS + s) * 2 + 0) * C + c];
+            a1 += part2[(((size_t)g * RS + s) * 2 + 1) * C + c];
         }
-        __syncthreads();
+        sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
+        sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
+        t0 += a0; t1 += a1;
     }
-    if (rl == 0 && c < C) {
-        if (dbeta) dbeta[c] = (float)t0;
-        if (dgamma) dgamma[c] = (float)t1;
-    }
+    if (dbeta) dbeta[c] = (float)t0;
+    if (dgamma) dgamma[c] = (float)t1;
 }
 
 // dz = scale * (g - s0/M - xhat * s1/M)
@@ -245,7 +235,8 @@ extern "C" size_t bdn_bn_bwd_workspace_bytes(int dtype, int N, int H, int W, int
     const int ppg = imgs_per_group * H * W;
     const int ppb = bnb_pix_per_block(ppg, 256 / (C / epu));
     const size_t blocks = (size_t)(N / imgs_per_group) * ((ppg + ppb - 1) / ppb);
-    return blocks * 2 * C * sizeof(float);
+    // float per-block partials, then (8-byte aligned) the double scratch of the second reduction stage
+    return ((blocks * 2 * C * sizeof(float) + 7) / 8) * 8 + (size_t)(N / imgs_per_group) * 64 * 2 * C * sizeof(double);
 }
 
 template <typename T>
@@ -259,7 +250,11 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(G * bpg), dim3(256), 256 * EPU * 2 * sizeof(float), st,
                        (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, ppb, C, ws);
     BDN_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, bpg, G, C, sums, dgamma, dbeta);
+    double* part2 = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)G * bpg * 2 * C * sizeof(float) + 7) / 8) * 8);
+    const RowPlan rp = row_plan(bpg);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64, G, rp.RS), dim3(256), 0, st, ws, bpg, rp.rps, rp.RS, C, part2);
+    BDN_CHECK_LAUNCH("bn_bwd_reduce_rows");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part2, rp.RS, G, C, sums, dgamma, dbeta);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
                        (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);

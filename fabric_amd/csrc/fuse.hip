@@ -169,8 +169,10 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dU, int ldU, T* __re
         float o[EPU];
 #pragma unroll
         for (int i = 0; i < EPU; i++) o[i] = 0.f;
-        const int ylo = max(0, 2 * y - 3), yhi = min(2 * h - 1, 2 * y + 5);
-        const int xlo = max(0, 2 * x - 3), xhi = min(2 * w - 1, 2 * x + 5);
+        // destination d reads sources floor(s)+{0,1} with s = d*(n-1)/(2n-1) in (d/2 - 1/2, d/2]: only
+        // d in [2y-2, 2y+3] can touch source y (one spare on each side for float rounding)
+        const int ylo = max(0, 2 * y - 2), yhi = min(2 * h - 1, 2 * y + 3);
+        const int xlo = max(0, 2 * x - 2), xhi = min(2 * w - 1, 2 * x + 3);
         for (int dy = ylo; dy <= yhi; dy++) {
             int a0, a1; float ly; up_tap(dy, h, sy, a0, a1, ly);
             const float wy = (a0 == y ? 1.f - ly : 0.f) + (a1 == y ? ly : 0.f);

@@ -60,6 +60,31 @@ extern "C" int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* 
     return BDN_OK;
 }
 
+// all layers in one launch: desc[l] = {w, wf, wd, Cout, Cin, Cin_pad}; grid.y = layer
+struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, Cinp, pad_; };
+template <typename T>
+__global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ desc) {
+    const PackDesc d = desc[blockIdx.y];
+    const size_t total = (size_t)d.Cout * 9 * d.Cinp;
+    T* wf = reinterpret_cast<T*>(d.wf); T* wd = reinterpret_cast<T*>(d.wd);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = i % d.Cinp; const size_t t = i / d.Cinp; const int tap = t % 9; const int co = t / 9;
+        const float v = ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + tap] : 0.f;
+        if (wf) wf[i] = from_f<T>(v);
+        if (wd) wd[((size_t)ci * 9 + (8 - tap)) * d.Cout + co] = from_f<T>(v);
+    }
+}
+
+extern "C" int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stream) {
+    if (!desc || n_layers <= 0) BDN_FAIL(BDN_E_ARG, "pack_weights_multi: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_weights_multi_kernel<bf16s>, dim3(256, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3(256, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
+    else BDN_FAIL(BDN_E_ARG, "pack_weights_multi: bad dtype");
+    BDN_CHECK_LAUNCH("pack_weights_multi");
+    return BDN_OK;
+}
+
 // ============================================================ outconv 1x1 (unet_parts.py:86)
 constexpr int OUTC_MAXCLS = 8;
 template <typename T>

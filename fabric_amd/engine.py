@@ -150,7 +150,10 @@ class BiDateEngine:
         self.cp = _round_up(n_channels, 16)
         self.layers = build_layers(n_channels)
         self._ws = {}
-        self._packed = {}          # conv prefix -> (version key, wf, wd)
+        self._packed = {}          # conv prefix -> (wf, wd) packed GEMM images
+        self._packed_valid = False
+        self._pack_desc = None
+        self._packed_versions = None
         self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
 
@@ -192,19 +195,34 @@ class BiDateEngine:
         return self._ws[key]
 
     def _weights(self, L, P, need_wd):
-        w = P[f'{L.conv}.weight']
-        key = (w.data_ptr(), w._version, str(w.device))
-        ent = self._packed.get(L.conv)
-        if ent is None or ent[0] != key:
-            wf = torch.empty(L.cout, 9, L.cin, dtype=self.tdtype, device=w.device)
-            wd = torch.empty(L.cin, 9, L.cout, dtype=self.tdtype, device=w.device) if L.name != 'e1a' else None
-            call('bdn_pack_weights', self.dt, ptr(w), ptr(wf), ptr(wd), L.cout, L.cin_real, L.cin, _lib.stream_ptr())
-            ent = (key, wf, wd)
-            self._packed[L.conv] = ent
-        return ent[1], ent[2]
+        """Packed GEMM images of layer L (forward image, data-gradient image).  All 18 layers are (re)packed by
+        ONE launch whenever any master weight changed since the last pack."""
+        if not self._packed_valid:
+            self._pack_all(P)
+        ent = self._packed[L.conv]
+        return ent[0], ent[1]
+
+    def _pack_all(self, P):
+        import struct
+        ptrs = tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)
+        if self._pack_desc is None or self._pack_desc[0] != ptrs:
+            dev = P[f'{self.layers[0].conv}.weight'].device
+            rec = b''
+            self._packed = {}
+            for L in self.layers:
+                wf = torch.empty(L.cout, 9, L.cin, dtype=self.tdtype, device=dev)
+                wd = torch.empty(L.cin, 9, L.cout, dtype=self.tdtype, device=dev) if L.name != 'e1a' else None
+                self._packed[L.conv] = (wf, wd)
+                rec += struct.pack('<QQQiiii', P[f'{L.conv}.weight'].data_ptr(), wf.data_ptr(),
+                                   wd.data_ptr() if wd is not None else 0, L.cout, L.cin_real, L.cin, 0)
+            desc = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+            self._pack_desc = (ptrs, desc)
+        call('bdn_pack_weights_multi', self.dt, ptr(self._pack_desc[1]), len(self.layers), _lib.stream_ptr())
+        self._packed_versions = tuple(P[f'{L.conv}.weight']._version for L in self.layers)
+        self._packed_valid = True
 
     def invalidate_weights(self):
-        self._packed.clear()
+        self._packed_valid = False
 
     def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st):
         hk, wk = ws.dims[L.level - 1]
@@ -243,6 +261,8 @@ class BiDateEngine:
         ws = self.workspace(B, H, W, dev)
         st = _lib.stream_ptr()
         by = {L.name: L for L in self.layers}
+        if self._packed_valid and self._packed_versions != tuple(P[f'{L.conv}.weight']._version for L in self.layers):
+            self._packed_valid = False            # an optimizer touched the master weights
         call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, st)
         # ---- shared encoder on both dates (2B images, 2 statistic groups)
         for k in range(1, 6):

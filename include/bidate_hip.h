@@ -46,6 +46,10 @@ int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,
 int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
                      int Cout, int Cin, int Cin_pad, void* stream);
 
+/* The same for n_layers filters in one launch.  desc: DEVICE array of n_layers records
+ * { const float* w_oihw; void* wf; void* wd; int32 Cout, Cin, Cin_pad, reserved; } (40 bytes each). */
+int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stream);
+
 /* ---- 3x3 convolution, stride 1, zero padding 1: nn.Conv2d(ci,co,3,padding=1), models/unet_parts.py:13,16 ----
  * Implicit GEMM on MFMA.  The A operand is gathered from in0 (channels [0,C0)) and optionally in1
  * (channels [C0,C0+C1), the never-materialised torch.cat of models/unet_parts.py:78).
