@@ -23,11 +23,18 @@ template <> struct ET<float> { static constexpr int EPU = 4; };   // elements pe
 template <> struct ET<bf16s> { static constexpr int EPU = 8; };
 
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {            // round to nearest even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+// round to nearest even through the hardware converter (v_cvt_pk_bf16_f32); a bit-twiddling version with a
+// NaN branch cost a divergent exec-mask sequence per element in every staging loop
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t f2bf(float f) {
+    __bf16 r = (__bf16)f;
+    return (uint32_t)__builtin_bit_cast(uint16_t, r);
+}
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {  // two values -> one packed dword
+    f32x2_t v = {lo, hi};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16s v) { return bf2f(v); }
@@ -56,8 +63,7 @@ template <> struct Unit<bf16s> {
         f[6] = bf2f(u.w & 0xffffu); f[7] = bf2f(u.w >> 16);
     }
     __device__ __forceinline__ static uint4 pack(const float* f) {
-        return make_uint4(f2bf(f[0]) | (f2bf(f[1]) << 16), f2bf(f[2]) | (f2bf(f[3]) << 16),
-                          f2bf(f[4]) | (f2bf(f[5]) << 16), f2bf(f[6]) | (f2bf(f[7]) << 16));
+        return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]), f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
     }
 };
 
