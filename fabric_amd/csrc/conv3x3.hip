@@ -14,7 +14,7 @@
 
 // experiment switches (defaults = shipped configuration)
 #ifndef F_SCHED
-#define F_SCHED 0      // pin the W / patch global loads at the top of the tap
+#define F_SCHED 1      // pin the W / patch global loads at the top of the tap
 #endif
 #ifndef F_FRAGDB
 #define F_FRAGDB 0     // fragment double buffer inside a tap
@@ -170,24 +170,38 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     // Plain unrolled code on purpose: a lambda capturing the register array by reference sent it to scratch.
     const T* wbase = reinterpret_cast<const T*>(a.w);
     constexpr bool W_EXACT = (BN * UPP) % 256 == 0;
-    uint4 wreg[NWU];
-    const T* wsrc[NWU];
-    int wdst[NWU];
-#pragma unroll
-    for (int i = 0; i < NWU; i++) {
-        const int u = tid + i * 256;
-        const int row = (W_EXACT || u < BN * UPP) ? u / UPP : 0, sub = u % UPP;
-        wsrc[i] = wbase + (size_t)(col0 + row) * 9 * Cin + sub * EPU;
-        wdst[i] = row * WSTR + sub * 16;
+    static_assert(NWU <= 4, "filter slice: at most four units per thread");
+    // named scalars, not an array: an array that meets a compiler memory fence (or a by-reference lambda)
+    // is kept in scratch memory
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+    const T* wsrc0; const T* wsrc1; const T* wsrc2; const T* wsrc3;
+    int wdst0, wdst1, wdst2, wdst3;
+    {
+        auto setup = [&](int i, const T*& src, int& dst) {
+            const int u = tid + i * 256;
+            const int row = (W_EXACT || u < BN * UPP) ? u / UPP : 0, sub = u % UPP;
+            src = wbase + (size_t)(col0 + row) * 9 * Cin + sub * EPU;
+            dst = row * WSTR + sub * 16;
+        };
+        setup(0, wsrc0, wdst0); setup(1, wsrc1, wdst1); setup(2, wsrc2, wdst2); setup(3, wsrc3, wdst3);
     }
+#define W_ON(i_) ((i_) < NWU && (W_EXACT || tid + (i_) * 256 < BN * UPP))
 #define LOAD_W(tap_, c0_)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < NWU; i++)                                                     \
-        if (W_EXACT || tid + i * 256 < BN * UPP)                                                        \
-            wreg[i] = *reinterpret_cast<const uint4*>(wsrc[i] + (size_t)(tap_) * Cin + (c0_));
+    {                                                                                                  \
+        const size_t o_ = (size_t)(tap_) * Cin + (c0_);                                                 \
+        if (W_ON(0)) w0 = *reinterpret_cast<const uint4*>(wsrc0 + o_);                                  \
+        if (W_ON(1)) w1 = *reinterpret_cast<const uint4*>(wsrc1 + o_);                                  \
+        if (W_ON(2)) w2 = *reinterpret_cast<const uint4*>(wsrc2 + o_);                                  \
+        if (W_ON(3)) w3 = *reinterpret_cast<const uint4*>(wsrc3 + o_);                                  \
+    }
 #define STORE_W(buf_)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NWU; i++)                                                     \
-        if (W_EXACT || tid + i * 256 < BN * UPP)                                                        \
-            *reinterpret_cast<uint4*>(wbuf + (buf_) * CF::WBUF_BYTES + wdst[i]) = wreg[i];
+    {                                                                                                  \
+        unsigned char* b_ = wbuf + (buf_) * CF::WBUF_BYTES;                                             \
+        if (W_ON(0)) *reinterpret_cast<uint4*>(b_ + wdst0) = w0;                                        \
+        if (W_ON(1)) *reinterpret_cast<uint4*>(b_ + wdst1) = w1;                                        \
+        if (W_ON(2)) *reinterpret_cast<uint4*>(b_ + wdst2) = w2;                                        \
+        if (W_ON(3)) *reinterpret_cast<uint4*>(b_ + wdst3) = w3;                                        \
+    }
 
     LOAD_PATCH(0)
     for (int c0 = 0; c0 < Cin; c0 += CK) {
@@ -203,8 +217,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             // MFMAs, right in front of their LDS store, which exposes the full L2 latency every tap)
             if (tap < 8) { LOAD_W(tap + 1, c0) }
             if (F_PREFP && tap == 5 && c0 + CK < Cin) { LOAD_PATCH(c0 + CK) }   // next chunk's activations: 3 taps of cover
-#if F_SCHED
+#if F_SCHED == 1
             __builtin_amdgcn_sched_barrier(0);
+#elif F_SCHED == 2
+            asm volatile("" ::: "memory");      // memory ops may not cross: keeps the global loads above the LDS reads
 #endif
             const unsigned char* wb = wbuf + (tap & 1) * CF::WBUF_BYTES;
             const int tapoff = (tap / 3) * ROWP + (tap % 3) * PSTR;
@@ -247,6 +263,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
 #undef LOAD_W
 #undef STORE_W
+#undef W_ON
 #undef LOAD_PATCH
 #undef STORE_PATCH
 

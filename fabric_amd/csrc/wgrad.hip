@@ -136,6 +136,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         STORE_CHUNK()
         __syncthreads();
         if (q + 1 < q_end) LOAD_CHUNK(q + 1)
+#ifndef WG_NOSCHED
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads above the MFMAs (the scheduler sinks them otherwise)
+#endif
 
         if constexpr (sizeof(T) == 2) {
             // lane's transposing-read role: pixel (lane&15)>>2 of a 4-pixel group, 4-channel piece (lane&3)
