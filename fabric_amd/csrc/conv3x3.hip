@@ -156,8 +156,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #define STORE_PATCH(c0_)                                                                                 \
     {                                                                                                   \
         const bool bn_ = a.in_bn != nullptr && (c0_) < a.C0;                                            \
-        const float* sc_ = bn_ ? bn_row(a.in_bn, grp, 2, a.C0) + (c0_) + p_sub : nullptr;               \
-        const float* sh_ = bn_ ? bn_row(a.in_bn, grp, 3, a.C0) + (c0_) + p_sub : nullptr;               \
+        float sc_[EPU], sh_[EPU];                          /* all units of a thread share one channel group */ \
+        if (bn_) {                                                                                      \
+            const float* ps_ = bn_row(a.in_bn, grp, 2, a.C0) + (c0_) + p_sub;                           \
+            const float* ph_ = bn_row(a.in_bn, grp, 3, a.C0) + (c0_) + p_sub;                           \
+            _Pragma("unroll") for (int e = 0; e < EPU; e++) { sc_[e] = ps_[e]; sh_[e] = ph_[e]; }        \
+        }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
             if (p_lds[i] >= 0) {                                                                        \
                 uint4 v_ = make_uint4(0, 0, 0, 0);                                                      \
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     unsigned char* otile = smem;
     float* red = reinterpret_cast<float*>(smem + CF::BM * CF::OSTR);
     const bool do_stats = a.stats_partial != nullptr;
+    const bool full_tile = (n0 + TI <= a.N) && (y0 + TH <= a.H) && (x0 + TW <= a.W);   // block-uniform
 #pragma unroll
     for (int nj = 0; nj < NJ; nj++) {
         const int col = (wn * NJ + nj) * 32 + l31;
@@ -281,8 +286,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int slot = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
-                const bool valid = (n0 + ti < a.N) && (y0 + py < a.H) && (x0 + px < a.W);
+                bool valid = true;
+                if (!full_tile) {
+                    int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
+                    valid = (n0 + ti < a.N) && (y0 + py < a.H) && (x0 + px < a.W);
+                }
                 const float v = acc[mi][nj][r] + bias;
                 if (valid) { s += v; q += v * v; }
                 *reinterpret_cast<T*>(otile + slot * CF::OSTR + col * CF::ES) = from_f<T>(v);

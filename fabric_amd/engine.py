@@ -296,12 +296,14 @@ class BiDateEngine:
         return logits, ws
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ws, dlogits, P, grads, on_ready=None):
+    def backward(self, ws, dlogits, P, grads, on_ready=None, zero_bias_grads=True):
         """Gradient of the last training-mode forward on `ws`.
 
         dlogits: [B,n_classes,H,W] float32.  grads: dict key -> preallocated float32 tensor (reference
         parameter shapes) that is OVERWRITTEN.  on_ready(keys) is called after the kernels producing
-        those gradients have been enqueued (used to launch gradient all-reduce buckets early)."""
+        those gradients have been enqueued (used to launch gradient all-reduce buckets early).
+        zero_bias_grads=False: the caller guarantees the conv-bias gradient tensors already hold zeros (nobody
+        ever writes them), which saves 18 fill launches per step."""
         B, H, W = ws.B, ws.H, ws.W
         dev = dlogits.device
         dlogits = dlogits.contiguous().float()
@@ -323,7 +325,8 @@ class BiDateEngine:
             hk, wk = ws.dims[L.level - 1]
             call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
                  ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, st)
-            grads[f'{L.conv}.bias'].zero_()          # feeds a BatchNorm: gradient is identically zero
+            if zero_bias_grads:                      # feeds a BatchNorm: gradient is identically zero
+                grads[f'{L.conv}.bias'].zero_()
             ready([f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias'])
 
         def dgrad(L, dz, n, ipg):

@@ -71,7 +71,7 @@ class TrainStep:
         st = _lib.stream_ptr()
         _lib.call('bdn_tversky', logits.data_ptr(), labels.data_ptr(), float(self.alpha), float(self.beta),
                   float(self.eps), tvws.data_ptr(), loss.data_ptr(), counts.data_ptr(), dlogits.data_ptr(), B, C, H, W, st)
-        eng.backward(ws, dlogits, P, self.grads, on_ready=self.bucketer.on_ready)
+        eng.backward(ws, dlogits, P, self.grads, on_ready=self.bucketer.on_ready, zero_bias_grads=False)
         self.bucketer.finish()
         # p -= lr * (sum of rank gradients) / world : per-rank loss, averaged gradients (standard DDP)
         _lib.call('bdn_sgd_step', self.flat_params.data_ptr(), self.flat_grads.data_ptr(), float(self.lr),
