@@ -126,7 +126,7 @@ extern "C" int bdn_bn_eval(const float* gamma, const float* beta, const float* r
 // ---------------------------------------------------------------- backward (BatchNorm2d + ReLU)
 // Thread t owns channel unit t % CU and pixel lane t / CU (CU = C / EPU divides 256); a block covers
 // pix_per_block pixels of ONE group.
-constexpr int BNB_MAXPIX = 2048;    // upper bound of pixels per block (workspace sizing)
+constexpr int BNB_MAXBLOCKS = 1024; // per-group partial rows (enough blocks to saturate HBM; one-stage finalize below)
 
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
@@ -166,25 +166,40 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dA, int ldA, const T*
     }
 }
 
-// second stage of the two-stage row reduction: part2[g][s][2][C] (double) -> sums[g][2][C]; dgamma / dbeta are
-// summed over groups
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part2, int RS, int G, int C,
+// per-block partials [G*bpg][2][C] (bpg <= 1024 rows per group) -> sums[g][2][C]; dgamma / dbeta are summed over
+// groups.  1024 threads = 64 row lanes x 16 channels, double accumulation, fixed order.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks_per_group, int G, int C,
                                        float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sm[64][16][2];
+    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + cl;
     double t0 = 0.0, t1 = 0.0;
     for (int g = 0; g < G; g++) {
         double a0 = 0.0, a1 = 0.0;
-        for (int s = 0; s < RS; s++) {
-            a0 += part2[(((size_t)g * RS + s) * 2 + 0) * C + c];
-            a1 += part2[(((size_t)g * RS + s) * 2 + 1) * C + c];
+        if (c < C)
+            for (int r = rl; r < blocks_per_group; r += 64) {
+                const size_t row = (size_t)g * blocks_per_group + r;
+                a0 += partial[(row * 2 + 0) * C + c];
+                a1 += partial[(row * 2 + 1) * C + c];
+            }
+        sm[rl][cl][0] = a0; sm[rl][cl][1] = a1;
+        __syncthreads();
+        for (int st = 32; st >= 1; st >>= 1) {              // fixed-shape tree over the 64 row lanes
+            if (rl < st) { sm[rl][cl][0] += sm[rl + st][cl][0]; sm[rl][cl][1] += sm[rl + st][cl][1]; }
+            __syncthreads();
         }
-        sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
-        sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
-        t0 += a0; t1 += a1;
+        if (rl == 0 && c < C) {
+            a0 = sm[0][cl][0]; a1 = sm[0][cl][1];
+            sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
+            sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
+            t0 += a0; t1 += a1;
+        }
+        __syncthreads();
     }
-    if (dbeta) dbeta[c] = (float)t0;
-    if (dgamma) dgamma[c] = (float)t1;
+    if (rl == 0 && c < C) {
+        if (dbeta) dbeta[c] = (float)t0;
+        if (dgamma) dgamma[c] = (float)t1;
+    }
 }
 
 // dz = scale * (g - s0/M - xhat * s1/M)
@@ -221,11 +236,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* 
     }
 }
 
-// pixels per block: ~1024 blocks per group for the big maps, never fewer than two pixel rows of the block
+// pixels per block: at most BNB_MAXBLOCKS blocks per group, never fewer than two pixel rows of the block
 static inline int bnb_pix_per_block(int pix_per_group, int rows) {
-    int p = (pix_per_group + 1023) / 1024;
+    int p = (pix_per_group + BNB_MAXBLOCKS - 1) / BNB_MAXBLOCKS;
     if (p < 2 * rows) p = 2 * rows;
-    if (p > BNB_MAXPIX) p = BNB_MAXPIX;
     return (p + rows - 1) / rows * rows;
 }
 
@@ -235,8 +249,7 @@ extern "C" size_t bdn_bn_bwd_workspace_bytes(int dtype, int N, int H, int W, int
     const int ppg = imgs_per_group * H * W;
     const int ppb = bnb_pix_per_block(ppg, 256 / (C / epu));
     const size_t blocks = (size_t)(N / imgs_per_group) * ((ppg + ppb - 1) / ppb);
-    // float per-block partials, then (8-byte aligned) the double scratch of the second reduction stage
-    return ((blocks * 2 * C * sizeof(float) + 7) / 8) * 8 + (size_t)(N / imgs_per_group) * 64 * 2 * C * sizeof(double);
+    return blocks * 2 * C * sizeof(float);
 }
 
 template <typename T>
@@ -250,11 +263,7 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(G * bpg), dim3(256), 256 * EPU * 2 * sizeof(float), st,
                        (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, ppb, C, ws);
     BDN_CHECK_LAUNCH("bn_bwd_reduce");
-    double* part2 = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(ws) + (((size_t)G * bpg * 2 * C * sizeof(float) + 7) / 8) * 8);
-    const RowPlan rp = row_plan(bpg);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64, G, rp.RS), dim3(256), 0, st, ws, bpg, rp.rps, rp.RS, C, part2);
-    BDN_CHECK_LAUNCH("bn_bwd_reduce_rows");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part2, rp.RS, G, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, ws, bpg, G, C, sums, dgamma, dbeta);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
                        (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
