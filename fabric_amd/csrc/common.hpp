@@ -83,6 +83,18 @@ __device__ __forceinline__ uint4 bnrelu_unit(const uint4& u, const float* sc, co
     return Unit<T>::pack(f);
 }
 
+// Filter image in MFMA fragment order (what conv3x3_kernel streams from L2): one contiguous 1 KB record per
+// (32 output channels, tap, k-group of 32 bytes of input channels); inside a record lane l owns 16 bytes:
+// output channel 32*cb + (l & 31), input channels kgroup*KCH + (l >> 5)*EPU + [0, EPU).
+// Returns the element index of weight (co, tap, c) for a filter with Cin (padded) input channels.
+template <typename T>
+__host__ __device__ __forceinline__ size_t wfrag_index(int co, int tap, int c, int Cin) {
+    constexpr int EPU = 16 / (int)sizeof(T), KCH = 32 / (int)sizeof(T);
+    const size_t rec = ((size_t)(co >> 5) * 9 + tap) * (Cin / KCH) + c / KCH;
+    const int lane = (co & 31) + 32 * ((c % KCH) / EPU);
+    return rec * (64 * EPU) + lane * EPU + c % EPU;
+}
+
 // XCD-aware bijective block remap: consecutive logical ids stay on one XCD (private L2)
 __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;

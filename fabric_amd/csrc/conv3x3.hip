@@ -3,37 +3,28 @@
 // (reference models/unet_parts.py:13,16 and autograd thereof).
 //
 // GEMM view: M = N*H*W output pixels, N = Cout, K = 9*Cin.
-// One 256-thread block (4 waves) owns BM = 128 output pixels (a TI x TH x TW spatial tile)
-// x BN output channels.  Per channel chunk the (TH+2)x(TW+2) halo patch is staged ONCE into
-// LDS (BatchNorm+ReLU of the producer applied on the way in); the nine taps then read it at
-// shifted pixel offsets, so activations cross HBM/L2 -> LDS once instead of nine times.
-// The filter slice of one tap x chunk is double-buffered through registers -> LDS.
-// Epilogue: + bias, per-tile sum / sum^2 for the following BatchNorm, transpose through
-// LDS, 16-byte coalesced NHWC stores.
+// One 256-thread block (4 waves) owns a TI x TH x TW spatial tile (128 or 256 output pixels) x BN output
+// channels; each wave a 64 x 64 (or 64 x 32) sub-tile of v_mfma_f32_32x32x16_bf16 / 32x32x2_f32.
+//   A operand (activations): per channel chunk the (TH+2)x(TW+2) halo patch is staged ONCE into LDS
+//     (BatchNorm+ReLU of the producer applied on the way in, next chunk prefetched through registers into
+//     the second LDS buffer); the nine taps read it at shifted pixel offsets, so activations cross
+//     HBM/L2 -> LDS once instead of nine times.  Pixel stride and row pitch are padded so every
+//     ds_read_b128 lane group hits disjoint banks.
+//   B operand (filters): never touches LDS.  The filters are tiny (<= 9.4 MB), shared by every block and
+//     L2/MALL resident, so they are packed once per step in MFMA *fragment order* (one contiguous 1 KB
+//     record per 32 output channels x tap x k-group) and each wave streams its fragments straight from
+//     L2 into registers, one tap ahead of the MFMAs.  This removes the per-tap filter staging, its LDS
+//     writes, half of all LDS fragment reads and eight of the nine barriers per chunk (LDS bandwidth was
+//     the co-limiter of the LDS-staged version: 96 % busy at 50 % MFMA).
+// Epilogue: + bias, per-tile sum / sum^2 for the following BatchNorm, transpose through LDS, 16-byte
+// coalesced NHWC stores.  Block ids are remapped so the N-tiles of one M-tile share an XCD's L2.
 #include "common.hpp"
-
-// experiment switches (defaults = shipped configuration)
-#ifndef F_SCHED
-#define F_SCHED 1      // pin the W / patch global loads at the top of the tap
-#endif
-#ifndef F_FRAGDB
-#define F_FRAGDB 0     // fragment double buffer inside a tap
-#endif
-#ifndef F_PREFP
-#define F_PREFP 1      // prefetch the next chunk's patch into registers
-#endif
-#ifndef F_ROWPAD
-#define F_ROWPAD 1     // bank-conflict-free patch row pitch
-#endif
-#ifndef F_LB2
-#define F_LB2 1        // __launch_bounds__(256, 2)
-#endif
 
 struct ConvArgs {
     const void* in0; const void* in1; int C0, C1;
     const float* in_bn;          // [G][4][C0] or null
     int imgs_per_group;
-    const void* w;               // [Cout][9][Cin]
+    const void* w;               // fragment-ordered filter image (common.hpp: wfrag_index)
     const float* bias;           // [Cout] or null
     void* out;                   // [N,H,W,Cout]
     float* stats_partial;        // [n_mtiles][2][Cout] or null
@@ -70,21 +61,20 @@ struct ConvCfg {
     // LDS row pitch: a 16-lane ds_read_b128 group spans two (TW=16) or four (TW=8) patch rows; the row
     // pitch is padded so that those rows land on disjoint bank slots (pitch/16 = 0 resp. 8 mod 16).
     static constexpr int ROWSLOTS = TL::PW * (PSTR / 16);
-    static constexpr int RPAD = F_ROWPAD ? (((TW == 16 ? 0 : 8) - ROWSLOTS % 16 + 16) % 16) * 16 : 0;
+    static constexpr int RPAD = (((TW == 16 ? 0 : 8) - ROWSLOTS % 16 + 16) % 16) * 16;
     static constexpr int ROWP = TL::PW * PSTR + RPAD;
-    static constexpr int WSTR = CKB + 16;
     static constexpr int MI = BM / (WM * 32), NJ = BN / (WN * 32);
-    static constexpr int KG = CKB / 32;
+    static constexpr int KG = CKB / 32;                // k-groups (32 bytes of channels) per chunk
     static constexpr int PATCH_BYTES = TI * TL::PH * ROWP;
-    static constexpr int WBUF_BYTES = BN * WSTR;
+    static constexpr int PBUF = (2 * PATCH_BYTES <= 56 * 1024) ? 2 : 1;   // double-buffer when two blocks still fit a CU
     static constexpr int OSTR = BN * ES + 16;
-    static constexpr int NWU = (BN * UPP + 255) / 256;
     static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
-    static constexpr int MAIN_BYTES = PATCH_BYTES + 2 * WBUF_BYTES;
+    static constexpr int MAIN_BYTES = PBUF * PATCH_BYTES;
     static constexpr int EPI_BYTES = BM * OSTR + WM * BN * 2 * 4;
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
+    static_assert(NJ <= 2 && KG <= 4, "filter fragment registers are named scalars");
     __device__ __forceinline__ static int slot_off(int s) {       // LDS byte offset of a slot's (r=0,c=0) tap
         int ti, py, px; TL::slot_to_nyx(s, ti, py, px);
         return (ti * TL::PH + py) * ROWP + px * PSTR;
@@ -92,18 +82,12 @@ struct ConvCfg {
 };
 
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN>
-#if F_LB2
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
-#else
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
-#endif
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
     using TL = typename CF::TL;
-    constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, WSTR = CF::WSTR, ROWP = CF::ROWP;
-    constexpr int EPU = CF::EPU, UPP = CF::UPP, NWU = CF::NWU, NPU = CF::NPU, CK = CF::CK;
+    constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
+    constexpr int EPU = CF::EPU, UPP = CF::UPP, NPU = CF::NPU, CK = CF::CK, PBUF = CF::PBUF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* patch = smem;
-    unsigned char* wbuf = smem + CF::PATCH_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -116,12 +100,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     const int Cin = a.C0 + a.C1;
     const int grp = n0 / a.imgs_per_group;
 
-    // per-lane LDS offsets of the A rows (pixel slots) and B rows (output channels)
-    int a_off[MI], b_off[NJ];
+    int a_off[MI];                                       // per-lane LDS offsets of the A rows (pixel slots)
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) a_off[mi] = CF::slot_off((wm * MI + mi) * 32 + l31) + half * 16;
-#pragma unroll
-    for (int nj = 0; nj < NJ; nj++) b_off[nj] = ((wn * NJ + nj) * 32 + l31) * WSTR + half * 16;
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -132,7 +113,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             for (int r = 0; r < 16; r++) acc[mi][nj][r] = 0.f;
 
     // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
-    int p_pix[NPU], p_lds[NPU];                          // global pixel index (-1 = zero padding), LDS byte offset
+    int p_pix[NPU];                                      // global pixel index of each unit (-1 = zero padding)
 #pragma unroll
     for (int i = 0; i < NPU; i++) {
         const int u = tid + i * 256;
@@ -141,7 +122,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         const int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
         const bool ok = u < TL::NPIX * UPP && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
         p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
-        p_lds[i] = u < TL::NPIX * UPP ? (ti * TL::PH + yy) * ROWP + xx * PSTR + sub * 16 : -1;
     }
     const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
     uint4 preg[NPU];
@@ -153,8 +133,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
             if (p_pix[i] >= 0) preg[i] = *reinterpret_cast<const uint4*>(src_ + (size_t)p_pix[i] * Cs_ + cs_ + p_sub); \
     }
-#define STORE_PATCH(c0_)                                                                                 \
+#define STORE_PATCH(c0_, buf_)                                                                           \
     {                                                                                                   \
+        unsigned char* pb_ = smem + (buf_) * CF::PATCH_BYTES;                                           \
         const bool bn_ = a.in_bn != nullptr && (c0_) < a.C0;                                            \
         float sc_[EPU], sh_[EPU];                          /* all units of a thread share one channel group */ \
         if (bn_) {                                                                                      \
@@ -162,112 +143,89 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             const float* ph_ = bn_row(a.in_bn, grp, 3, a.C0) + (c0_) + p_sub;                           \
             _Pragma("unroll") for (int e = 0; e < EPU; e++) { sc_[e] = ps_[e]; sh_[e] = ph_[e]; }        \
         }                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
-            if (p_lds[i] >= 0) {                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
+            const int u_ = tid + i * 256;                  /* LDS offset recomputed: cheaper than 11 live registers */ \
+            if (u_ < TL::NPIX * UPP) {                                                                  \
+                const int pix_ = u_ / UPP, xx_ = pix_ % TL::PW, t_ = pix_ / TL::PW;                      \
                 uint4 v_ = make_uint4(0, 0, 0, 0);                                                      \
                 if (p_pix[i] >= 0) v_ = bn_ ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];              \
-                *reinterpret_cast<uint4*>(patch + p_lds[i]) = v_;                                       \
+                *reinterpret_cast<uint4*>(pb_ + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = v_;          \
             }                                                                                           \
+        }                                                                                               \
     }
 
-    // ---- filter slice of one (tap, chunk): BN rows x CKB bytes, NWU units per thread, global -> regs -> LDS.
-    // Plain unrolled code on purpose: a lambda capturing the register array by reference sent it to scratch.
-    const T* wbase = reinterpret_cast<const T*>(a.w);
-    constexpr bool W_EXACT = (BN * UPP) % 256 == 0;
-    static_assert(NWU <= 4, "filter slice: at most four units per thread");
-    // named scalars, not an array: an array that meets a compiler memory fence (or a by-reference lambda)
-    // is kept in scratch memory
-    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
-    const T* wsrc0; const T* wsrc1; const T* wsrc2; const T* wsrc3;
-    int wdst0, wdst1, wdst2, wdst3;
-    {
-        auto setup = [&](int i, const T*& src, int& dst) {
-            const int u = tid + i * 256;
-            const int row = (W_EXACT || u < BN * UPP) ? u / UPP : 0, sub = u % UPP;
-            src = wbase + (size_t)(col0 + row) * 9 * Cin + sub * EPU;
-            dst = row * WSTR + sub * 16;
-        };
-        setup(0, wsrc0, wdst0); setup(1, wsrc1, wdst1); setup(2, wsrc2, wdst2); setup(3, wsrc3, wdst3);
+    // ---- filter fragments: per wave NJ x KG records of 1 KB (64 lanes x 16 B), streamed one tap ahead from
+    // the fragment-ordered image.  Named scalars on purpose (register arrays that meet a scheduling fence were
+    // kept in scratch).  Record index: ((cout/32 * 9 + tap) * Cin/KCH + c/KCH); see wfrag_index in common.hpp.
+    constexpr int KCH = 32 / CF::ES;                     // channels per k-group
+    const int kgroups = Cin / KCH;                       // records per (cout block, tap)
+    const unsigned char* wb0 = reinterpret_cast<const unsigned char*>(a.w)
+        + ((size_t)((col0 >> 5) + wn * NJ) * 9 * kgroups) * 1024 + lane * 16;
+    const unsigned char* wb1 = wb0 + (size_t)9 * kgroups * 1024;     // second cout block of this wave (NJ == 2)
+    uint4 bc00, bc01, bc02, bc03, bc10, bc11, bc12, bc13;            // current tap  [nj][kg]
+    uint4 bn00, bn01, bn02, bn03, bn10, bn11, bn12, bn13;            // next tap
+    bc00 = bc01 = bc02 = bc03 = bc10 = bc11 = bc12 = bc13 = make_uint4(0, 0, 0, 0);
+    bn00 = bn01 = bn02 = bn03 = bn10 = bn11 = bn12 = bn13 = make_uint4(0, 0, 0, 0);
+#define LDB(p_, k_) (*reinterpret_cast<const uint4*>((p_) + (k_) * 1024))
+#define LOAD_B_NEXT(rec_)                                                                                \
+    {                                                                                                   \
+        const unsigned char* q0_ = wb0 + (size_t)(rec_) * 1024;                                         \
+        bn00 = LDB(q0_, 0); if (KG > 1) bn01 = LDB(q0_, 1); if (KG > 2) bn02 = LDB(q0_, 2); if (KG > 3) bn03 = LDB(q0_, 3); \
+        if (NJ > 1) {                                                                                   \
+            const unsigned char* q1_ = wb1 + (size_t)(rec_) * 1024;                                     \
+            bn10 = LDB(q1_, 0); if (KG > 1) bn11 = LDB(q1_, 1); if (KG > 2) bn12 = LDB(q1_, 2); if (KG > 3) bn13 = LDB(q1_, 3); \
+        }                                                                                               \
     }
-#define W_ON(i_) ((i_) < NWU && (W_EXACT || tid + (i_) * 256 < BN * UPP))
-#define LOAD_W(tap_, c0_)                                                                              \
-    {                                                                                                  \
-        const size_t o_ = (size_t)(tap_) * Cin + (c0_);                                                 \
-        if (W_ON(0)) w0 = *reinterpret_cast<const uint4*>(wsrc0 + o_);                                  \
-        if (W_ON(1)) w1 = *reinterpret_cast<const uint4*>(wsrc1 + o_);                                  \
-        if (W_ON(2)) w2 = *reinterpret_cast<const uint4*>(wsrc2 + o_);                                  \
-        if (W_ON(3)) w3 = *reinterpret_cast<const uint4*>(wsrc3 + o_);                                  \
-    }
-#define STORE_W(buf_)                                                                                  \
-    {                                                                                                  \
-        unsigned char* b_ = wbuf + (buf_) * CF::WBUF_BYTES;                                             \
-        if (W_ON(0)) *reinterpret_cast<uint4*>(b_ + wdst0) = w0;                                        \
-        if (W_ON(1)) *reinterpret_cast<uint4*>(b_ + wdst1) = w1;                                        \
-        if (W_ON(2)) *reinterpret_cast<uint4*>(b_ + wdst2) = w2;                                        \
-        if (W_ON(3)) *reinterpret_cast<uint4*>(b_ + wdst3) = w3;                                        \
+#define ROTATE_B() { bc00 = bn00; bc01 = bn01; bc02 = bn02; bc03 = bn03; bc10 = bn10; bc11 = bn11; bc12 = bn12; bc13 = bn13; }
+#define MMA_KG(kg_, b0_, b1_)                                                                            \
+    if ((kg_) < KG) {                                                                                   \
+        uint4 af_[MI];                                                                                  \
+        _Pragma("unroll") for (int mi = 0; mi < MI; mi++)                                                \
+            af_[mi] = *reinterpret_cast<const uint4*>(pcur + a_off[mi] + tapoff + (kg_) * 32);           \
+        _Pragma("unroll") for (int mi = 0; mi < MI; mi++) {                                              \
+            Mma<T>::run(af_[mi], b0_, acc[mi][0]);                                                      \
+            if (NJ > 1) Mma<T>::run(af_[mi], b1_, acc[mi][NJ - 1]);                                     \
+        }                                                                                               \
     }
 
+    // prologue: first patch -> LDS buffer 0, first tap's filters -> registers
     LOAD_PATCH(0)
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
-        // LDS is free here: the previous chunk ended with a barrier
-        if (!F_PREFP && c0 > 0) { LOAD_PATCH(c0) }
-        STORE_PATCH(c0)
-        LOAD_W(0, c0)
-        STORE_W(0)
-        __syncthreads();
+    LOAD_B_NEXT(0)
+    STORE_PATCH(0, 0)
+    ROTATE_B()
+    __syncthreads();
+
+    int chunk = 0;
+    for (int c0 = 0; c0 < Cin; c0 += CK, chunk++) {
+        const unsigned char* pcur = smem + (PBUF == 2 ? (chunk & 1) : 0) * CF::PATCH_BYTES;
+        const bool more = c0 + CK < Cin;
+        const int rec0 = chunk * KG;                     // record offset of this chunk inside a (cout block, tap) row
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            // issue the global loads FIRST and pin them there (left alone, the scheduler sinks them below the
-            // MFMAs, right in front of their LDS store, which exposes the full L2 latency every tap)
-            if (tap < 8) { LOAD_W(tap + 1, c0) }
-            if (F_PREFP && tap == 5 && c0 + CK < Cin) { LOAD_PATCH(c0 + CK) }   // next chunk's activations: 3 taps of cover
-#if F_SCHED == 1
+            // next tap's filter fragments (tap 0 of the next chunk after tap 8) and, early in the chunk, the next
+            // chunk's activations: issue the global loads first and pin them above the MFMAs
+            if (tap < 8) { LOAD_B_NEXT((tap + 1) * kgroups + rec0) }
+            else if (more) { LOAD_B_NEXT(rec0 + KG) }
+            if (tap == 1 && more) { LOAD_PATCH(c0 + CK) }
             __builtin_amdgcn_sched_barrier(0);
-#elif F_SCHED == 2
-            asm volatile("" ::: "memory");      // memory ops may not cross: keeps the global loads above the LDS reads
-#endif
-            const unsigned char* wb = wbuf + (tap & 1) * CF::WBUF_BYTES;
             const int tapoff = (tap / 3) * ROWP + (tap % 3) * PSTR;
-#if F_FRAGDB
-            uint4 fa[2][MI], fb[2][NJ];                  // fragment double buffer: reads of k-group g+1 fly under MFMAs of g
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) fa[0][mi] = *reinterpret_cast<const uint4*>(patch + a_off[mi] + tapoff);
-#pragma unroll
-            for (int nj = 0; nj < NJ; nj++) fb[0][nj] = *reinterpret_cast<const uint4*>(wb + b_off[nj]);
-#pragma unroll
-            for (int kg = 0; kg < KG; kg++) {
-                if (kg + 1 < KG) {
-#pragma unroll
-                    for (int mi = 0; mi < MI; mi++) fa[(kg + 1) & 1][mi] = *reinterpret_cast<const uint4*>(patch + a_off[mi] + tapoff + (kg + 1) * 32);
-#pragma unroll
-                    for (int nj = 0; nj < NJ; nj++) fb[(kg + 1) & 1][nj] = *reinterpret_cast<const uint4*>(wb + b_off[nj] + (kg + 1) * 32);
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int nj = 0; nj < NJ; nj++) Mma<T>::run(fa[kg & 1][mi], fb[kg & 1][nj], acc[mi][nj]);
-            }
-#else
-#pragma unroll
-            for (int kg = 0; kg < KG; kg++) {
-                uint4 af[MI], bf[NJ];
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const uint4*>(patch + a_off[mi] + tapoff + kg * 32);
-#pragma unroll
-                for (int nj = 0; nj < NJ; nj++) bf[nj] = *reinterpret_cast<const uint4*>(wb + b_off[nj] + kg * 32);
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int nj = 0; nj < NJ; nj++) Mma<T>::run(af[mi], bf[nj], acc[mi][nj]);
-            }
-#endif
-            if (tap < 8) { STORE_W((tap + 1) & 1) }              // other buffer: last read before the previous barrier
-            __syncthreads();
+            MMA_KG(0, bc00, bc10)
+            MMA_KG(1, bc01, bc11)
+            MMA_KG(2, bc02, bc12)
+            MMA_KG(3, bc03, bc13)
+            if (PBUF == 2 && tap == 6 && more) { STORE_PATCH(c0 + CK, (chunk + 1) & 1) }   // other buffer: free since the last barrier
+            ROTATE_B()
         }
+        if (PBUF == 1 && more) {                         // single patch buffer: everyone done reading, then refill
+            __syncthreads();
+            STORE_PATCH(c0 + CK, 0)
+        }
+        __syncthreads();
     }
-#undef LOAD_W
-#undef STORE_W
-#undef W_ON
+#undef LDB
+#undef LOAD_B_NEXT
+#undef ROTATE_B
+#undef MMA_KG
 #undef LOAD_PATCH
 #undef STORE_PATCH
 
@@ -349,7 +307,9 @@ static ConvPlan conv_plan(int N, int H, int W, int Cout, int imgs_per_group) {
     TileGeom& g = p.g;
     const bool narrow = (Cout % 128 != 0);
     if (W <= 8 && H <= 8 && imgs_per_group % 2 == 0) { g.TI = 2; g.TH = 8; g.TW = 8; }
+#ifndef NO_T16
     else if (narrow && H >= 12 && W >= 12) { g.TI = 1; g.TH = 16; g.TW = 16; }
+#endif
     else { g.TI = 1; g.TH = 8; g.TW = 16; }
     g.tiles_y = (H + g.TH - 1) / g.TH;
     g.tiles_x = (W + g.TW - 1) / g.TW;

@@ -34,7 +34,9 @@ extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, v
 }
 
 // ============================================================ pack_weights
-// wf[co][tap][ci] = w[co][ci][r][c];  wd[ci][tap][co] = w[co][ci][2-r][2-c]   (tap = 3r+c)
+// forward image:        W_f(co, tap, ci) = w[co][ci][r][c]               (tap = 3r+c)
+// data-gradient image:  W_d(ci, tap, co) = w[co][ci][2-r][2-c]  i.e. the transposed filter with taps rotated 180 deg
+// both stored in MFMA fragment order (common.hpp: wfrag_index); Cout and Cin_pad are multiples of 32 / 16.
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
                                     int Cout, int Cin, int Cinp) {
@@ -43,14 +45,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     if (i >= total) return;
     const int ci = i % Cinp; const size_t t = i / Cinp; const int tap = t % 9; const int co = t / 9;
     const float v = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
-    if (wf) wf[i] = from_f<T>(v);
-    if (wd) wd[((size_t)ci * 9 + (8 - tap)) * Cout + co] = from_f<T>(v);
+    if (wf) wf[wfrag_index<T>(co, tap, ci, Cinp)] = from_f<T>(v);
+    if (wd) wd[wfrag_index<T>(ci, 8 - tap, co, Cout)] = from_f<T>(v);
 }
 
 extern "C" int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
                                 int Cout, int Cin, int Cin_pad, void* stream) {
     if (!w_oihw || (!wf && !wd)) BDN_FAIL(BDN_E_ARG, "pack_weights: null pointer");
-    if (Cout <= 0 || Cin <= 0 || Cin_pad < Cin) BDN_FAIL(BDN_E_SHAPE, "pack_weights: bad shape");
+    if (Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cout % 32 || Cin_pad % 16 || (wd && Cin_pad % 32))
+        BDN_FAIL(BDN_E_SHAPE, "pack_weights: Cout must be a multiple of 32, Cin_pad of 16 (32 with a data-gradient image)");
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)Cout * 9 * Cin_pad;
     if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16s>, dim3(grid_for(total)), dim3(256), 0, st, w_oihw, (bf16s*)wf, (bf16s*)wd, Cout, Cin, Cin_pad);
@@ -70,8 +73,8 @@ __global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ desc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ci = i % d.Cinp; const size_t t = i / d.Cinp; const int tap = t % 9; const int co = t / 9;
         const float v = ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + tap] : 0.f;
-        if (wf) wf[i] = from_f<T>(v);
-        if (wd) wd[((size_t)ci * 9 + (8 - tap)) * d.Cout + co] = from_f<T>(v);
+        if (wf) wf[wfrag_index<T>(co, tap, ci, d.Cinp)] = from_f<T>(v);
+        if (wd) wd[wfrag_index<T>(ci, 8 - tap, co, d.Cout)] = from_f<T>(v);
     }
 }
 

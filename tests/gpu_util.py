@@ -47,14 +47,29 @@ def assert_close(name, got, ref, rel, abs_floor=0.0):
     return d, r
 
 
+def frag_to_dense(precision, wfrag, cout, cin):
+    """Inverse of the fragment-order filter image (csrc/common.hpp: wfrag_index) -> [cout][9][cin] float32 CPU."""
+    es = 2 if precision == 'bf16' else 4
+    epu, kch = 16 // es, 32 // es
+    flat = wfrag.float().cpu().reshape(-1)
+    co = torch.arange(cout)[:, None, None]
+    tap = torch.arange(9)[None, :, None]
+    c = torch.arange(cin)[None, None, :]
+    rec = ((co // 32) * 9 + tap) * (cin // kch) + c // kch
+    lane = (co % 32) + 32 * ((c % kch) // epu)
+    idx = rec * (64 * epu) + lane * epu + c % epu
+    return flat[idx]
+
+
 def pack_w(precision, w_oihw, cin_pad):
     """Run bdn_pack_weights; returns (wf, wd) device tensors."""
     dt, td = DT[precision]
     co, ci = w_oihw.shape[:2]
     wdev = dev(w_oihw)
     wf = torch.empty(co, 9, cin_pad, dtype=td, device='cuda')
-    wd = torch.empty(cin_pad, 9, co, dtype=td, device='cuda')
-    _lib.call('bdn_pack_weights', dt, wdev.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, cin_pad, st())
+    wd = torch.empty(cin_pad, 9, co, dtype=td, device='cuda') if cin_pad % 32 == 0 else None   # dgrad image: Cin_pad % 32
+    _lib.call('bdn_pack_weights', dt, wdev.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else None,
+              co, ci, cin_pad, st())
     return wf, wd
 
 

@@ -12,7 +12,8 @@ import torch.nn.functional as F
 from fabric_amd import _lib
 from fabric_amd._lib import IN_BNRELU, IN_PLAIN
 from oracle import bidate_oracle as O
-from tests.gpu_util import (DT, assert_close, bn_table, bnrelu_ref, dev, from_nhwc, pack_w, rnd, st, to_nhwc)
+from tests.gpu_util import (DT, assert_close, bn_table, bnrelu_ref, dev, frag_to_dense, from_nhwc, pack_w, rnd, st,
+                            to_nhwc)
 
 pytestmark = pytest.mark.gpu
 TOL = {'fp32': 2e-5, 'bf16': 1e-2}
@@ -397,14 +398,17 @@ def test_pack_input_and_weights(prec):
     got = from_nhwc(out)
     ref = rnd(prec, torch.cat([x1, x2]))
     assert torch.equal(got[:, :C], ref) and (got[:, C:] == 0).all()
+    Cp2 = 32                                      # the data-gradient image needs Cin_pad % 32 == 0
     w = _rand((64, C, 3, 3), 83)
-    wf, wd = pack_w(prec, w, Cp)
+    wf, wd = pack_w(prec, w, Cp2)
     torch.cuda.synchronize()
     wr = rnd(prec, w)
-    assert torch.equal(wf.float().cpu()[:, :, :C], wr.permute(0, 2, 3, 1).reshape(64, 9, C))
-    assert (wf.float().cpu()[:, :, C:] == 0).all()
+    dense_f = frag_to_dense(prec, wf, 64, Cp2)                      # [co][tap][ci]
+    assert torch.equal(dense_f[:, :, :C], wr.permute(0, 2, 3, 1).reshape(64, 9, C))
+    assert (dense_f[:, :, C:] == 0).all()
+    dense_d = frag_to_dense(prec, wd, Cp2, 64)                      # [ci][tap][co], taps rotated by 180 degrees
     rot = torch.flip(wr, (2, 3)).permute(1, 2, 3, 0).reshape(C, 9, 64)
-    assert torch.equal(wd.float().cpu()[:C], rot)
+    assert torch.equal(dense_d[:C], rot) and (dense_d[C:] == 0).all()
 
 
 def test_sgd_step():
