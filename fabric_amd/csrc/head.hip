@@ -65,16 +65,26 @@ extern "C" int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* 
 
 // all layers in one launch: desc[l] = {w, wf, wd, Cout, Cin, Cin_pad}; grid.y = layer
 struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, Cinp, pad_; };
+// one thread per OUTPUT element (coalesced 2/4-byte writes in fragment order; the strided reads of the
+// 54 MB fp32 master hit L2)
 template <typename T>
 __global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ desc) {
+    constexpr int EPU = 16 / (int)sizeof(T), KCH = 32 / (int)sizeof(T), REC = 64 * EPU;
     const PackDesc d = desc[blockIdx.y];
     const size_t total = (size_t)d.Cout * 9 * d.Cinp;
     T* wf = reinterpret_cast<T*>(d.wf); T* wd = reinterpret_cast<T*>(d.wd);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ci = i % d.Cinp; const size_t t = i / d.Cinp; const int tap = t % 9; const int co = t / 9;
-        const float v = ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + tap] : 0.f;
-        if (wf) wf[wfrag_index<T>(co, tap, ci, d.Cinp)] = from_f<T>(v);
-        if (wd) wd[wfrag_index<T>(ci, 8 - tap, co, d.Cout)] = from_f<T>(v);
+        const int e = i % EPU, lane = (i / EPU) % 64; const size_t rec = i / REC;
+        if (wf) {       // rec = (cb*9 + tap)*(Cinp/KCH) + kgi
+            const int kgi = rec % (d.Cinp / KCH); const size_t t = rec / (d.Cinp / KCH); const int tap = t % 9, cb = t / 9;
+            const int co = cb * 32 + (lane & 31), ci = kgi * KCH + (lane >> 5) * EPU + e;
+            wf[i] = from_f<T>(ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + tap] : 0.f);
+        }
+        if (wd) {       // roles swapped: "cout" = ci (padded), "cin" = co; taps rotated by 180 degrees
+            const int kgi = rec % (d.Cout / KCH); const size_t t = rec / (d.Cout / KCH); const int tap = t % 9, cb = t / 9;
+            const int ci = cb * 32 + (lane & 31), co = kgi * KCH + (lane >> 5) * EPU + e;
+            wd[i] = from_f<T>(ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + (8 - tap)] : 0.f);
+        }
     }
 }
 
@@ -127,63 +137,73 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
 }
 
 // backward: dA[p][c] = sum_k dl[k][p] w[k][c];  dw[k][c] = sum_p dl[k][p] a[p][c];  db[k] = sum_p dl[k][p]
-// block = 256 pixels; dw/db block partials are combined with f32 atomics on a zeroed buffer (130 addresses).
+// Thread t owns channel unit t % CU (its filter taps, BN constants and dw accumulators live in registers)
+// and walks pixels t / CU, +rows, ...; block partials of dw/db are combined with f32 atomics on a zeroed
+// buffer (ncls*(C+1) addresses) -- the only float atomics on the training path.
+constexpr int OUTC_ITERS = 16;
 template <typename T>
-__global__ void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
+__global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
                                 const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ dw, float* __restrict__ db,
-                                int B, int H, int W, int C, int ncls) {
+                                int npix, int hw, int C, int ncls) {
     constexpr int EPU = ET<T>::EPU;
     extern __shared__ float sm[];                             // [ncls][C+1] block accumulators
-    const size_t npix = (size_t)B * H * W, hw = (size_t)H * W;
-    for (int i = threadIdx.x; i < ncls * (C + 1); i += blockDim.x) sm[i] = 0.f;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    for (int i = tid; i < ncls * (C + 1); i += 256) sm[i] = 0.f;
+    float sc[EPU], sh[EPU], wk[OUTC_MAXCLS][EPU], acc[OUTC_MAXCLS][EPU], accb[OUTC_MAXCLS];
+#pragma unroll
+    for (int i = 0; i < EPU; i++) { sc[i] = bn_row(bn, 0, 2, C)[c + i]; sh[i] = bn_row(bn, 0, 3, C)[c + i]; }
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXCLS; k++) {
+        accb[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPU; i++) { wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f; acc[k][i] = 0.f; }
+    }
     __syncthreads();
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float g[OUTC_MAXCLS];
-    const bool live = p < npix;
-    if (live) { const size_t b = p / hw, q = p % hw;
-        for (int k = 0; k < ncls; k++) g[k] = dl[(b * ncls + k) * hw + q]; }
-    else for (int k = 0; k < ncls; k++) g[k] = 0.f;
-    for (int c = 0; c < C; c += EPU) {
-        float f[EPU], o[EPU];
-        if (live) Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p * C + c), f);
+    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_ITERS);
+    for (int p = blockIdx.x * rows * OUTC_ITERS + row; p < p_end; p += rows) {
+        const int b = p / hw, q = p % hw;
+        float g[OUTC_MAXCLS], f[EPU], o[EPU];
+#pragma unroll
+        for (int k = 0; k < OUTC_MAXCLS; k++) g[k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), f);
 #pragma unroll
         for (int i = 0; i < EPU; i++) {
-            const float a = live ? to_f(from_f<T>(fmaxf(fmaf(f[i], bn_row(bn, 0, 2, C)[c + i], bn_row(bn, 0, 3, C)[c + i]), 0.f))) : 0.f;
+            const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
             float s = 0.f;
-            for (int k = 0; k < ncls; k++) {
-                s = fmaf(g[k], w[k * C + c + i], s);
-                float v = g[k] * a;                           // wave-reduce before touching LDS
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if ((threadIdx.x & 63) == 0) atomicAdd(&sm[k * (C + 1) + c + i], v);
-            }
+            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
             o[i] = s;
         }
-        if (live) *reinterpret_cast<uint4*>(dA + p * C + c) = Unit<T>::pack(o);
+        if (cu == 0) {
+#pragma unroll
+            for (int k = 0; k < OUTC_MAXCLS; k++) accb[k] += g[k];
+        }
+        *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = Unit<T>::pack(o);
     }
     for (int k = 0; k < ncls; k++) {
-        float v = g[k];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&sm[k * (C + 1) + C], v);
+        for (int i = 0; i < EPU; i++) atomicAdd(&sm[k * (C + 1) + c + i], acc[k][i]);   // LDS atomics: `rows` adds per address
+        if (cu == 0) atomicAdd(&sm[k * (C + 1) + C], accb[k]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ncls * (C + 1); i += blockDim.x) {
-        const int k = i / (C + 1), c = i % (C + 1);
-        if (c < C) atomicAdd(&dw[k * C + c], sm[i]); else atomicAdd(&db[k], sm[i]);
+    for (int i = tid; i < ncls * (C + 1); i += 256) {
+        const int k = i / (C + 1), cc = i % (C + 1);
+        if (cc < C) atomicAdd(&dw[k * C + cc], sm[i]); else atomicAdd(&db[k], sm[i]);
     }
 }
 
 extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
                             void* dA, float* dw, float* db, int B, int H, int W, int C, int ncls, void* stream) {
     if (!dlogits || !z || !bn || !w || !dA || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
-    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
-    hipStream_t st = (hipStream_t)stream; const size_t npix = (size_t)B * H * W;
+    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream; const int npix = B * H * W;
     hipMemsetAsync(dw, 0, sizeof(float) * ncls * C, st);
     hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
     const size_t smem = sizeof(float) * ncls * (C + 1);
-    if (dtype == BDN_BF16) hipLaunchKernelGGL(outc_bwd_kernel<bf16s>, dim3(grid_for(npix)), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, B, H, W, C, ncls);
-    else if (dtype == BDN_F32) hipLaunchKernelGGL(outc_bwd_kernel<float>, dim3(grid_for(npix)), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, B, H, W, C, ncls);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * OUTC_ITERS;
+        hipLaunchKernelGGL(outc_bwd_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, npix, H * W, C, ncls); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * OUTC_ITERS;
+        hipLaunchKernelGGL(outc_bwd_kernel<float>, dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, npix, H * W, C, ncls); }
     else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
     return BDN_OK;
