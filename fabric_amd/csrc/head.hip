@@ -100,37 +100,61 @@ extern "C" int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers,
 
 // ============================================================ outconv 1x1 (unet_parts.py:86)
 constexpr int OUTC_MAXCLS = 8;
-template <typename T>
+constexpr int OUTC_ITERS = 16;      // pixels per thread in the classifier kernels
+// NC = compile-time class-count bound (2 for the change / no-change head, 8 generic): loops over classes unroll
+// without runtime predicates.  CU = C/EPU consecutive lanes share one pixel (each reads 16 contiguous bytes ->
+// fully coalesced), partial dot products are combined with xor-shuffles inside the CU-lane group.
+template <typename T, int NC>
 __global__ void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ w,
-                                const float* __restrict__ bias, float* __restrict__ logits, int B, int H, int W, int C, int ncls) {
+                                const float* __restrict__ bias, float* __restrict__ logits, int npix, int hw, int C, int ncls) {
     constexpr int EPU = ET<T>::EPU;
-    const size_t npix = (size_t)B * H * W;
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    float acc[OUTC_MAXCLS];
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    float sc[EPU], sh[EPU], wk[NC][EPU];
 #pragma unroll
-    for (int k = 0; k < OUTC_MAXCLS; k++) acc[k] = k < ncls ? bias[k] : 0.f;
-    for (int c = 0; c < C; c += EPU) {
-        float f[EPU];
-        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p * C + c), f);
+    for (int i = 0; i < EPU; i++) { sc[i] = bn_row(bn, 0, 2, C)[c + i]; sh[i] = bn_row(bn, 0, 3, C)[c + i]; }
 #pragma unroll
-        for (int i = 0; i < EPU; i++) {
-            const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], bn_row(bn, 0, 2, C)[c + i], bn_row(bn, 0, 3, C)[c + i]), 0.f)));
+    for (int k = 0; k < NC; k++)
 #pragma unroll
-            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) acc[k] = fmaf(a, w[k * C + c + i], acc[k]);
+        for (int i = 0; i < EPU; i++) wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f;
+    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_ITERS);
+    for (int p0 = blockIdx.x * rows * OUTC_ITERS; p0 < p_end; p0 += rows) {       // block-uniform trip count
+        const int p = p0 + row;
+        float f[EPU], acc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) acc[k] = 0.f;
+        if (p < p_end) {
+            Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), f);
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
+#pragma unroll
+                for (int k = 0; k < NC; k++) acc[k] = fmaf(a, wk[k][i], acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            for (int off = CU >> 1; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+        if (cu == 0 && p < p_end) {
+            const int b = p / hw, q = p % hw;
+            for (int k = 0; k < ncls; k++) logits[((size_t)b * ncls + k) * hw + q] = acc[k] + bias[k];
         }
     }
-    const size_t hw = (size_t)H * W; const size_t b = p / hw, q = p % hw;
-    for (int k = 0; k < ncls; k++) logits[(b * ncls + k) * hw + q] = acc[k];
 }
 
 extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, const float* b,
                             float* logits, int B, int H, int W, int C, int ncls, void* stream) {
     if (!z || !bn || !w || !b || !logits) BDN_FAIL(BDN_E_ARG, "outc_fwd: null pointer");
-    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16) BDN_FAIL(BDN_E_SHAPE, "outc_fwd: ncls=%d (max %d), C=%d", ncls, OUTC_MAXCLS, C);
-    hipStream_t st = (hipStream_t)stream; const size_t npix = (size_t)B * H * W;
-    if (dtype == BDN_BF16) hipLaunchKernelGGL(outc_fwd_kernel<bf16s>, dim3(grid_for(npix)), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, B, H, W, C, ncls);
-    else if (dtype == BDN_F32) hipLaunchKernelGGL(outc_fwd_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, st, (const float*)z, bn, w, b, logits, B, H, W, C, ncls);
+    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 512 || 512 % C) BDN_FAIL(BDN_E_SHAPE, "outc_fwd: ncls=%d (max %d), C=%d", ncls, OUTC_MAXCLS, C);
+    hipStream_t st = (hipStream_t)stream; const int npix = B * H * W, hw = H * W;
+    if (dtype == BDN_BF16) {
+        const int per = 256 / (C / 8) * OUTC_ITERS; const unsigned grid = (npix + per - 1) / per;
+        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<bf16s, 2>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls);
+        else hipLaunchKernelGGL((outc_fwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls);
+    } else if (dtype == BDN_F32) {
+        const int per = 256 / (C / 4) * OUTC_ITERS; const unsigned grid = (npix + per - 1) / per;
+        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls);
+        else hipLaunchKernelGGL((outc_fwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls);
+    }
     else BDN_FAIL(BDN_E_ARG, "outc_fwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_fwd");
     return BDN_OK;
@@ -140,8 +164,7 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
 // Thread t owns channel unit t % CU (its filter taps, BN constants and dw accumulators live in registers)
 // and walks pixels t / CU, +rows, ...; block partials of dw/db are combined with f32 atomics on a zeroed
 // buffer (ncls*(C+1) addresses) -- the only float atomics on the training path.
-constexpr int OUTC_ITERS = 16;
-template <typename T>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
                                 const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ dw, float* __restrict__ db,
                                 int npix, int hw, int C, int ncls) {
@@ -149,11 +172,11 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
     extern __shared__ float sm[];                             // [ncls][C+1] block accumulators
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     for (int i = tid; i < ncls * (C + 1); i += 256) sm[i] = 0.f;
-    float sc[EPU], sh[EPU], wk[OUTC_MAXCLS][EPU], acc[OUTC_MAXCLS][EPU], accb[OUTC_MAXCLS];
+    float sc[EPU], sh[EPU], wk[NC][EPU], acc[NC][EPU], accb[NC];
 #pragma unroll
     for (int i = 0; i < EPU; i++) { sc[i] = bn_row(bn, 0, 2, C)[c + i]; sh[i] = bn_row(bn, 0, 3, C)[c + i]; }
 #pragma unroll
-    for (int k = 0; k < OUTC_MAXCLS; k++) {
+    for (int k = 0; k < NC; k++) {
         accb[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < EPU; i++) { wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f; acc[k][i] = 0.f; }
@@ -162,21 +185,21 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
     const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_ITERS);
     for (int p = blockIdx.x * rows * OUTC_ITERS + row; p < p_end; p += rows) {
         const int b = p / hw, q = p % hw;
-        float g[OUTC_MAXCLS], f[EPU], o[EPU];
+        float g[NC], f[EPU], o[EPU];
 #pragma unroll
-        for (int k = 0; k < OUTC_MAXCLS; k++) g[k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
+        for (int k = 0; k < NC; k++) g[k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
         Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), f);
 #pragma unroll
         for (int i = 0; i < EPU; i++) {
             const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
+            for (int k = 0; k < NC; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
             o[i] = s;
         }
         if (cu == 0) {
 #pragma unroll
-            for (int k = 0; k < OUTC_MAXCLS; k++) accb[k] += g[k];
+            for (int k = 0; k < NC; k++) accb[k] += g[k];
         }
         *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = Unit<T>::pack(o);
     }
@@ -201,9 +224,11 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
     hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
     const size_t smem = sizeof(float) * ncls * (C + 1);
     if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * OUTC_ITERS;
-        hipLaunchKernelGGL(outc_bwd_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, npix, H * W, C, ncls); }
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, npix, H * W, C, ncls);
+        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, npix, H * W, C, ncls); }
     else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * OUTC_ITERS;
-        hipLaunchKernelGGL(outc_bwd_kernel<float>, dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, npix, H * W, C, ncls); }
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, npix, H * W, C, ncls);
+        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, npix, H * W, C, ncls); }
     else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
     return BDN_OK;
@@ -213,47 +238,63 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
 // sums[k][c][w], k = 0 TP, 1 FP, 2 FN, reduced over batch and H for every (class, column w).
 // pass 1: grid (B*H rows) -> atomics on [3][ncls][W] (one add per row and address);  pass 2: single block
 // loss + coefficient tables;  pass 3: dlogits.
+template <int NC>
 __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
-                                    float* __restrict__ sums, int32_t* __restrict__ counts, int B, int ncls, int H, int W) {
-    // block = 256 threads = columns; grid.x = column blocks, grid.y = row groups of RG rows
-    constexpr int RG = 16;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+                                    float* __restrict__ sums, int32_t* __restrict__ counts, int B, int ncls, int H, int W,
+                                    int rows_per_block) {
+    // block = 256 threads = RL row lanes x CW columns (CW = min(W rounded up to a power of two, 256));
+    // grid.x = column blocks, grid.y = row blocks
+    extern __shared__ float sm[];                         // [RL][3*NC][CW]
+    const int CW = blockDim.y, RL = blockDim.x;           // launch: dim3(RL, CW) with x = row lane (slow), see host
+    const int cl = threadIdx.y, rl = threadIdx.x;
+    const int x = blockIdx.x * CW + cl;
     const size_t hw = (size_t)H * W;
-    float tp[OUTC_MAXCLS], fp[OUTC_MAXCLS], fn[OUTC_MAXCLS];
+    float tp[NC], fp[NC], fn[NC];
 #pragma unroll
-    for (int k = 0; k < OUTC_MAXCLS; k++) { tp[k] = 0.f; fp[k] = 0.f; fn[k] = 0.f; }
+    for (int k = 0; k < NC; k++) { tp[k] = 0.f; fp[k] = 0.f; fn[k] = 0.f; }
     int c_tp = 0, c_fp = 0, c_fn = 0, c_ok = 0;
-    const int rows = B * H;
+    const int rows = B * H, r_end = min(rows, (int)(blockIdx.y + 1) * rows_per_block);
     if (x < W)
-        for (int r = blockIdx.y * RG; r < min(rows, (blockIdx.y + 1) * RG); r++) {
+        for (int r = blockIdx.y * rows_per_block + rl; r < r_end; r += RL) {
             const int b = r / H, y = r % H;
             const size_t q = (size_t)y * W + x;
-            float l[OUTC_MAXCLS]; float m = -INFINITY; int am = 0;
+            float l[NC]; float m = -INFINITY; int am = 0;
 #pragma unroll
-            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = logits[((size_t)b * ncls + k) * hw + q]; if (l[k] > m) { m = l[k]; am = k; } }
+            for (int k = 0; k < NC; k++) { l[k] = k < ncls ? logits[((size_t)b * ncls + k) * hw + q] : -INFINITY; if (l[k] > m) { m = l[k]; am = k; } }
             float den = 0.f;
 #pragma unroll
-            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = expf(l[k] - m); den += l[k]; }
+            for (int k = 0; k < NC; k++) { l[k] = k < ncls ? expf(l[k] - m) : 0.f; den += l[k]; }
             const int t = labels[(size_t)b * hw + q];
+            const float inv = 1.f / den;
 #pragma unroll
-            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) {
-                const float p = l[k] / den;
+            for (int k = 0; k < NC; k++) {
+                const float p = l[k] * inv;
                 if (t == k) { tp[k] += p; fn[k] += 1.f - p; } else fp[k] += p;
             }
             c_tp += (am == 1 && t == 1); c_fp += (am == 1 && t != 1); c_fn += (am != 1 && t == 1); c_ok += (am == t);
         }
-    if (x < W)
-        for (int k = 0; k < ncls; k++) {
-            atomicAdd(&sums[(0 * ncls + k) * W + x], tp[k]);
-            atomicAdd(&sums[(1 * ncls + k) * W + x], fp[k]);
-            atomicAdd(&sums[(2 * ncls + k) * W + x], fn[k]);
-        }
-    if (counts) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            c_tp += __shfl_xor(c_tp, off); c_fp += __shfl_xor(c_fp, off); c_fn += __shfl_xor(c_fn, off); c_ok += __shfl_xor(c_ok, off);
-        }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], c_tp); atomicAdd(&counts[1], c_fp); atomicAdd(&counts[2], c_fn); atomicAdd(&counts[3], c_ok); }
+    for (int k = 0; k < NC; k++) {
+        sm[(rl * 3 * NC + 0 * NC + k) * CW + cl] = tp[k];
+        sm[(rl * 3 * NC + 1 * NC + k) * CW + cl] = fp[k];
+        sm[(rl * 3 * NC + 2 * NC + k) * CW + cl] = fn[k];
+    }
+    __syncthreads();
+    if (rl == 0 && x < W)
+        for (int k = 0; k < ncls; k++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float v = 0.f;
+                for (int r = 0; r < RL; r++) v += sm[(r * 3 * NC + j * NC + k) * CW + cl];
+                atomicAdd(&sums[(j * ncls + k) * W + x], v);
+            }
+    if (counts) {
+        int* ism = reinterpret_cast<int*>(sm);
+        __syncthreads();
+        const int tid = rl * CW + cl;
+        ism[tid * 4 + 0] = c_tp; ism[tid * 4 + 1] = c_fp; ism[tid * 4 + 2] = c_fn; ism[tid * 4 + 3] = c_ok;
+        __syncthreads();
+        if (tid < 4) { int v = 0; for (int i = 0; i < 256; i++) v += ism[i * 4 + tid]; atomicAdd(&counts[tid], v); }
     }
 }
 
@@ -311,8 +352,12 @@ extern "C" int bdn_tversky(const float* logits, const uint8_t* labels, float alp
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * W, st);
     if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
-    dim3 grid((W + 255) / 256, (B * H + 15) / 16);
-    hipLaunchKernelGGL(tversky_sums_kernel, grid, dim3(256), 0, st, logits, labels, ws, counts, B, ncls, H, W);
+    int CW = 1; while (CW < W && CW < 256) CW *= 2;
+    const int RL = 256 / CW, rows = B * H;
+    int rpb = (rows + 255) / 256; if (rpb < RL) rpb = RL;                       // ~256 row blocks
+    dim3 grid((W + CW - 1) / CW, (rows + rpb - 1) / rpb), block(RL, CW);
+    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, ws, counts, B, ncls, H, W, rpb);
+    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, ws, counts, B, ncls, H, W, rpb);
     BDN_CHECK_LAUNCH("tversky_sums");
     hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(256), 0, st, ws, alpha, beta, eps, ncls, W, loss);
     BDN_CHECK_LAUNCH("tversky_finish");
