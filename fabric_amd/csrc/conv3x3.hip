@@ -74,7 +74,7 @@ struct ConvCfg {
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
-    static_assert(NJ <= 2 && KG <= 4, "filter fragment registers are named scalars");
+    static_assert(NJ <= 2 && (KG == 1 || KG == 2 || KG == 4), "filter fragment registers are named scalars");
     __device__ __forceinline__ static int slot_off(int s) {       // LDS byte offset of a slot's (r=0,c=0) tap
         int ti, py, px; TL::slot_to_nyx(s, ti, py, px);
         return (ti * TL::PH + py) * ROWP + px * PSTR;
@@ -162,23 +162,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     const unsigned char* wb0 = reinterpret_cast<const unsigned char*>(a.w)
         + ((size_t)((col0 >> 5) + wn * NJ) * 9 * kgroups) * 1024 + lane * 16;
     const unsigned char* wb1 = wb0 + (size_t)9 * kgroups * 1024;     // second cout block of this wave (NJ == 2)
-    uint4 bc00, bc01, bc02, bc03, bc10, bc11, bc12, bc13;            // current tap  [nj][kg]
-    uint4 bn00, bn01, bn02, bn03, bn10, bn11, bn12, bn13;            // next tap
-    bc00 = bc01 = bc02 = bc03 = bc10 = bc11 = bc12 = bc13 = make_uint4(0, 0, 0, 0);
-    bn00 = bn01 = bn02 = bn03 = bn10 = bn11 = bn12 = bn13 = make_uint4(0, 0, 0, 0);
+    // Ring of three register sets r0/r1/r2, one per STEP (= half a tap when a chunk has four k-groups, a whole
+    // tap otherwise).  Step s computes from ring[s % 3] while the loads of step s+2 land in ring[(s+2) % 3];
+    // a chunk has 9 or 18 steps (multiples of 3), so every index is a compile-time constant, nothing is
+    // ever copied, and the prefetch distance is one full tap (two for the short chunks).
+    constexpr int SPT = (KG == 4) ? 2 : 1;               // steps per tap
+    constexpr int KPS = KG / SPT;                        // k-groups per step (1 or 2)
+    constexpr int NST = 9 * SPT;                         // steps per chunk
+    static_assert(KPS <= 2 && NST % 3 == 0, "ring layout");
+    uint4 r0_00, r0_01, r0_10, r0_11, r1_00, r1_01, r1_10, r1_11, r2_00, r2_01, r2_10, r2_11;   // [nj][kps]
+    r0_00 = r0_01 = r0_10 = r0_11 = r1_00 = r1_01 = r1_10 = r1_11 = r2_00 = r2_01 = r2_10 = r2_11 = make_uint4(0, 0, 0, 0);
 #define LDB(p_, k_) (*reinterpret_cast<const uint4*>((p_) + (k_) * 1024))
-#define LOAD_B_NEXT(rec_)                                                                                \
+    // load the fragments of step st_ (tap st_/SPT, k-groups (st_%SPT)*KPS ...) of the chunk whose record offset is rec_
+#define LOAD_R(R, st_, rec_)                                                                             \
     {                                                                                                   \
-        const unsigned char* q0_ = wb0 + (size_t)(rec_) * 1024;                                         \
-        bn00 = LDB(q0_, 0); if (KG > 1) bn01 = LDB(q0_, 1); if (KG > 2) bn02 = LDB(q0_, 2); if (KG > 3) bn03 = LDB(q0_, 3); \
-        if (NJ > 1) {                                                                                   \
-            const unsigned char* q1_ = wb1 + (size_t)(rec_) * 1024;                                     \
-            bn10 = LDB(q1_, 0); if (KG > 1) bn11 = LDB(q1_, 1); if (KG > 2) bn12 = LDB(q1_, 2); if (KG > 3) bn13 = LDB(q1_, 3); \
-        }                                                                                               \
+        const size_t o_ = ((size_t)((st_) / SPT) * kgroups + (rec_) + ((st_) % SPT) * KPS) * 1024;       \
+        R##_00 = LDB(wb0 + o_, 0); if (KPS > 1) R##_01 = LDB(wb0 + o_, 1);                              \
+        if (NJ > 1) { R##_10 = LDB(wb1 + o_, 0); if (KPS > 1) R##_11 = LDB(wb1 + o_, 1); }              \
     }
-#define ROTATE_B() { bc00 = bn00; bc01 = bn01; bc02 = bn02; bc03 = bn03; bc10 = bn10; bc11 = bn11; bc12 = bn12; bc13 = bn13; }
 #define MMA_KG(kg_, b0_, b1_)                                                                            \
-    if ((kg_) < KG) {                                                                                   \
+    {                                                                                                   \
         uint4 af_[MI];                                                                                  \
         _Pragma("unroll") for (int mi = 0; mi < MI; mi++)                                                \
             af_[mi] = *reinterpret_cast<const uint4*>(pcur + a_off[mi] + tapoff + (kg_) * 32);           \
@@ -187,12 +190,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
             if (NJ > 1) Mma<T>::run(af_[mi], b1_, acc[mi][NJ - 1]);                                     \
         }                                                                                               \
     }
+    // one step: RC holds this step's filters, RN receives those of step st_+2 (wrapping into the next chunk).
+    // Global loads are issued first and pinned above the MFMAs.
+#define STEP(st_, RC, RN)                                                                                \
+    {                                                                                                   \
+        if ((st_) + 2 < NST) { LOAD_R(RN, (st_) + 2, rec0) }                                            \
+        else if (more) { LOAD_R(RN, (st_) + 2 - NST, rec0 + KG) }                                       \
+        if ((st_) == SPT && more) { LOAD_PATCH(c0 + CK) }                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        const int tapoff = (((st_) / SPT) / 3) * ROWP + (((st_) / SPT) % 3) * PSTR;                     \
+        MMA_KG(((st_) % SPT) * KPS, RC##_00, RC##_10)                                                   \
+        if (KPS > 1) MMA_KG(((st_) % SPT) * KPS + 1, RC##_01, RC##_11)                                  \
+        if (PBUF == 2 && (st_) == 6 * SPT && more) { STORE_PATCH(c0 + CK, (chunk + 1) & 1) }            \
+    }
+#define STEP3(s_) STEP((s_), r0, r2) STEP((s_) + 1, r1, r0) STEP((s_) + 2, r2, r1)
 
-    // prologue: first patch -> LDS buffer 0, first tap's filters -> registers
+    // prologue: first patch -> LDS buffer 0, steps 0 and 1 -> ring slots 0 and 1
     LOAD_PATCH(0)
-    LOAD_B_NEXT(0)
+    LOAD_R(r0, 0, 0)
+    LOAD_R(r1, 1, 0)
     STORE_PATCH(0, 0)
-    ROTATE_B()
     __syncthreads();
 
     int chunk = 0;
@@ -200,22 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         const unsigned char* pcur = smem + (PBUF == 2 ? (chunk & 1) : 0) * CF::PATCH_BYTES;
         const bool more = c0 + CK < Cin;
         const int rec0 = chunk * KG;                     // record offset of this chunk inside a (cout block, tap) row
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            // next tap's filter fragments (tap 0 of the next chunk after tap 8) and, early in the chunk, the next
-            // chunk's activations: issue the global loads first and pin them above the MFMAs
-            if (tap < 8) { LOAD_B_NEXT((tap + 1) * kgroups + rec0) }
-            else if (more) { LOAD_B_NEXT(rec0 + KG) }
-            if (tap == 1 && more) { LOAD_PATCH(c0 + CK) }
-            __builtin_amdgcn_sched_barrier(0);
-            const int tapoff = (tap / 3) * ROWP + (tap % 3) * PSTR;
-            MMA_KG(0, bc00, bc10)
-            MMA_KG(1, bc01, bc11)
-            MMA_KG(2, bc02, bc12)
-            MMA_KG(3, bc03, bc13)
-            if (PBUF == 2 && tap == 6 && more) { STORE_PATCH(c0 + CK, (chunk + 1) & 1) }   // other buffer: free since the last barrier
-            ROTATE_B()
-        }
+        STEP3(0) STEP3(3) STEP3(6)
+        if constexpr (SPT == 2) { STEP3(9) STEP3(12) STEP3(15) }
         if (PBUF == 1 && more) {                         // single patch buffer: everyone done reading, then refill
             __syncthreads();
             STORE_PATCH(c0 + CK, 0)
@@ -223,8 +226,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         __syncthreads();
     }
 #undef LDB
-#undef LOAD_B_NEXT
-#undef ROTATE_B
+#undef LOAD_R
+#undef STEP
+#undef STEP3
 #undef MMA_KG
 #undef LOAD_PATCH
 #undef STORE_PATCH
