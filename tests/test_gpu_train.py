@@ -1,0 +1,62 @@
+"""-m gpu: the whole optimisation loop.  Several consecutive fused train steps (forward, Tversky, backward,
+SGD, BatchNorm running statistics) must follow the CPU oracle's trajectory, and the train.py-style epoch /
+validation helpers must report the reference's metric definitions (val F1 = mean of per-batch binary F1)."""
+import numpy as np
+import pytest
+import torch
+
+from fabric_amd import BiDateNet
+from fabric_amd.train_step import TrainStep
+from oracle import bidate_oracle as O
+from oracle import filler
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('prec,tol_logit,tol_loss', [('fp32', 2e-3, 2e-5), ('bf16', 0.3, 5e-3)])
+def test_five_steps_follow_the_oracle(prec, tol_logit, tol_loss):
+    c, b, s, steps, lr = 3, 4, 32, 5, 0.05          # large lr so that a wrong update would be visible
+    x1, x2, lbl = filler.make_inputs(b, c, s, seed=3)
+    x1, x2, lbl = torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl)
+    model = filler.fill_module(BiDateNet(c, 2, precision=prec))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    ts = TrainStep(model, lr=lr, tversky_alpha=0.1, tversky_beta=0.9)
+    dx1, dx2, dl = x1.cuda(), x2.cuda(), lbl.cuda()
+    for i in range(steps):
+        ref = O.train_step(sd, x1, x2, lbl, lr=lr, alpha=0.1, beta=0.9)
+        loss = ts.step(dx1, dx2, dl)
+        got_logits = ts.last_logits.cpu()
+        assert abs(loss.item() - float(ref['loss'])) < tol_loss * (i + 1), (i, loss.item(), float(ref['loss']))
+        assert (got_logits - ref['logits']).abs().max() < tol_logit * (i + 1), i
+        p_ref = O.binary_prf(lbl, ref['preds'])
+        from fabric_amd.utils.metrics import batch_prf_from_counts
+        p_got = batch_prf_from_counts(ts.last_counts.cpu())
+        assert np.allclose(p_got, p_ref, atol=2e-2 if prec == 'bf16' else 2e-3), (i, p_got, p_ref)
+        sd = ref['new_sd']
+    new = model.state_dict()
+    wtol = 2e-4 if prec == 'fp32' else 3e-2
+    for k, v in sd.items():
+        if v.is_floating_point():
+            assert (new[k].cpu() - v).abs().max() <= wtol * max(1.0, float(v.abs().max())), k
+        else:
+            assert int(new[k]) == int(v), k          # num_batches_tracked: 2 per step in the encoder, 1 in the decoder
+
+
+def test_epoch_and_validation_helpers():
+    from fabric_amd.train import make_loaders, train_epoch, validate
+    from fabric_amd.utils.dataloaders import synthetic_onera
+    torch.manual_seed(0)
+    data = synthetic_onera(n_cities=3, bands=13, size=(150, 150), seed=1, change_fraction=0.2)
+    tr, va = make_loaders(data, ['city2'], 64, 32, 4, augmentation=True)
+    model = BiDateNet(13, 2, precision='bf16').cuda()
+    step = TrainStep(model, lr=0.05, tversky_alpha=0.1, tversky_beta=0.9)
+    dev = torch.device('cuda')
+    m0 = train_epoch(step, tr, dev, 64)
+    m1 = train_epoch(step, tr, dev, 64)
+    assert set(m0) == {'cd_losses', 'cd_corrects', 'cd_precisions', 'cd_recalls', 'cd_f1scores'}
+    assert m1['cd_losses'] < m0['cd_losses']                    # it learns the synthetic change blobs
+    v = validate(model, va, dev, 64, 0.1, 0.9)
+    assert 0.0 <= v['cd_f1scores'] <= 1.0 and 0.0 <= v['cd_corrects'] <= 100.0
+    sd = model.state_dict()
+    assert int(sd['inc.conv.conv.1.num_batches_tracked']) == 2 * 2 * len(tr)   # eval passes leave the buffers alone
