@@ -66,6 +66,21 @@ def cpu_baseline(seconds_budget=25.0):
                       f'{threads} threads of {ncores} host CPUs'}
 
 
+def pmc_traffic(kernel, precision):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary is committed for this kernel."""
+    path = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+    if precision != 'bf16' or not os.path.exists(path):
+        return None
+    key = kernel.replace('bf16', 'unsigned short').replace(',', ', ')
+    rec = json.load(open(path)).get(key)
+    if not rec:
+        return None
+    return {'unit': 'bytes/launch', 'hbm_read': rec['fetch_bytes_per_launch_corrected'],
+            'hbm_write': rec['write_bytes_per_launch'], 'source': 'profiles/r1_pmc_traffic.json'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -147,7 +162,7 @@ def main():
         achieved = flops / secs
         conv_total = sum(v[2] for v in agg.values())
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved / 1e12, 'peak': peak / 1e12,
-                    'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_traffic(name, args.precision),
                     'launches_per_step': cnt / EVENT_STEPS, 'event_steps': EVENT_STEPS, 'avg_launch_us': secs / cnt * 1e6,
                     'flop_per_launch': flops / cnt,
                     'all_conv3x3_launches': {'time_frac_of_step': (conv_total / EVENT_STEPS) / (elapsed / args.steps),

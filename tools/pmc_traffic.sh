@@ -1,0 +1,27 @@
+#!/bin/bash
+# HBM traffic of every kernel of one bench run: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots),
+# kernel-trace/stats off (gpurun refuses --pmc with trace domains).  Output: gpurun_out/pmc_traffic.json
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmct
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmct/f -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/pmct_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmct/w -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/pmct_w.log 2>&1
+python - <<'PY'
+import csv, glob, json, collections
+out = collections.defaultdict(lambda: {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
+for kind in ('f', 'w'):
+    for f in glob.glob(f'gpurun_out/pmct/{kind}/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            out[k][r['Counter_Name']] += float(r['Counter_Value'])
+            if kind == 'f': out[k]['launches'] += 1
+res = {}
+for k, v in out.items():
+    n = max(1, v['launches'])
+    # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> x2
+    res[k] = {'launches': n, 'fetch_bytes_per_launch_raw': v['FETCH_SIZE'] * 1024 / n,
+              'fetch_bytes_per_launch_corrected': 2 * v['FETCH_SIZE'] * 1024 / n,
+              'write_bytes_per_launch': v['WRITE_SIZE'] * 1024 / n}
+json.dump(res, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
+for k in sorted(res, key=lambda k: -res[k]['fetch_bytes_per_launch_corrected'] * res[k]['launches'])[:8]:
+    print(k[:60], {a: round(b / 1e6, 1) if a != 'launches' else b for a, b in res[k].items()})
+PY
