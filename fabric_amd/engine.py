@@ -154,6 +154,7 @@ class BiDateEngine:
         self._packed_valid = False
         self._pack_desc = None
         self._packed_versions = None
+        self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
         self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
 
@@ -188,6 +189,12 @@ class BiDateEngine:
                           2.0 * n * h * w * cout * 9 * (c0 + c1), e0, e1))
 
     # ------------------------------------------------------------------ helpers
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
+
     def workspace(self, B, H, W, device):
         key = (B, H, W, str(device))
         if key not in self._ws:
@@ -296,14 +303,17 @@ class BiDateEngine:
         return logits, ws
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ws, dlogits, P, grads, on_ready=None, zero_bias_grads=True):
+    def backward(self, ws, dlogits, P, grads, on_ready=None, zero_bias_grads=True, wgrad_stream=True):
         """Gradient of the last training-mode forward on `ws`.
 
         dlogits: [B,n_classes,H,W] float32.  grads: dict key -> preallocated float32 tensor (reference
         parameter shapes) that is OVERWRITTEN.  on_ready(keys) is called after the kernels producing
         those gradients have been enqueued (used to launch gradient all-reduce buckets early).
         zero_bias_grads=False: the caller guarantees the conv-bias gradient tensors already hold zeros (nobody
-        ever writes them), which saves 18 fill launches per step."""
+        ever writes them), which saves 18 fill launches per step.
+        wgrad_stream=True: the weight-gradient GEMMs (off the critical dz -> dgrad -> dz chain, MFMA-bound) are
+        enqueued on a second HIP stream so they overlap the HBM-bound BatchNorm-backward / unpool / upsample
+        kernels of the chain; the main stream joins it before returning."""
         B, H, W = ws.B, ws.H, ws.W
         dev = dlogits.device
         dlogits = dlogits.contiguous().float()
@@ -313,6 +323,8 @@ class BiDateEngine:
         td, es = self.tdtype, self.esize
         e = lambda *s: torch.empty(*s, dtype=td, device=dev)
         ready = on_ready or (lambda keys: None)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if wgrad_stream else None
 
         def bn_bwd(L, dA, ldA, n, ipg):
             hk, wk = ws.dims[L.level - 1]
@@ -323,11 +335,23 @@ class BiDateEngine:
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
             hk, wk = ws.dims[L.level - 1]
-            call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
-                 ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, st)
-            if zero_bias_grads:                      # feeds a BatchNorm: gradient is identically zero
-                grads[f'{L.conv}.bias'].zero_()
-            ready([f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias'])
+            keys = [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias']
+            if side is None:
+                call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
+                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, st)
+                if zero_bias_grads:                  # feeds a BatchNorm: gradient is identically zero
+                    grads[f'{L.conv}.bias'].zero_()
+                ready(keys)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)                          # dz, the BatchNorm gradients and everything before them
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
+                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, side.cuda_stream)
+                if zero_bias_grads:
+                    grads[f'{L.conv}.bias'].zero_()
+                ready(keys)                          # a bucket all-reduce launched here is ordered behind this wgrad
 
         def dgrad(L, dz, n, ipg):
             hk, wk = ws.dims[L.level - 1]
@@ -391,4 +415,6 @@ class BiDateEngine:
             wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
             keep += [dAb, dzb, dAa, dza, dP]
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
+        if side is not None:
+            main.wait_stream(side)                   # every weight gradient is complete before the caller's next kernel
         return grads
