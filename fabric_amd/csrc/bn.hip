@@ -77,6 +77,49 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part2, int RS, int
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += G;
 }
 
+// One-launch variant for <= 2048 partial rows per group: 1024 threads = 64 row lanes x 16 channels reduce the
+// rows in double (fixed-shape tree), then the same finalize arithmetic as bn_finalize_kernel.
+__global__ __launch_bounds__(1024) void bn_finalize_direct_kernel(const float* __restrict__ partial, int rows_per_group, int G, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* nbt, float* __restrict__ bn) {
+    __shared__ double sm[64][16][2];
+    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + cl;
+    float rm = (running_mean && c < C) ? running_mean[c] : 0.f, rv = (running_var && c < C) ? running_var[c] : 0.f;
+    for (int g = 0; g < G; g++) {                         // sequential: running stats see date 1 then date 2
+        double a0 = 0.0, a1 = 0.0;
+        if (c < C)
+            for (int r = rl; r < rows_per_group; r += 64) {
+                const size_t row = (size_t)g * rows_per_group + r;
+                a0 += partial[(row * 2 + 0) * C + c];
+                a1 += partial[(row * 2 + 1) * C + c];
+            }
+        sm[rl][cl][0] = a0; sm[rl][cl][1] = a1;
+        __syncthreads();
+        for (int st = 32; st >= 1; st >>= 1) {
+            if (rl < st) { sm[rl][cl][0] += sm[rl + st][cl][0]; sm[rl][cl][1] += sm[rl + st][cl][1]; }
+            __syncthreads();
+        }
+        if (rl == 0 && c < C) {
+            const double mean = sm[0][cl][0] / count;
+            double var = sm[0][cl][1] / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float inv = (float)(1.0 / sqrt(var + (double)eps));
+            const float scale = gamma[c] * inv;
+            bn[((size_t)g * 4 + 0) * C + c] = (float)mean;
+            bn[((size_t)g * 4 + 1) * C + c] = inv;
+            bn[((size_t)g * 4 + 2) * C + c] = scale;
+            bn[((size_t)g * 4 + 3) * C + c] = beta[c] - (float)mean * scale;
+            const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * (float)unb;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < C && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += G;
+}
+
 extern "C" size_t bdn_bn_finalize_workspace_bytes(int n_mtiles, int G, int C) {
     if (n_mtiles <= 0 || G <= 0 || C <= 0) return 0;
     return (size_t)G * 64 * 2 * C * sizeof(double);
@@ -91,6 +134,12 @@ extern "C" int bdn_bn_finalize(const float* stats_partial, int n_mtiles, int G, 
     if ((running_mean == nullptr) != (running_var == nullptr)) BDN_FAIL(BDN_E_ARG, "bn_finalize: running_mean/var must come together");
     hipStream_t st = (hipStream_t)stream;
     const int rpg = n_mtiles / G;
+    if (rpg <= 2048) {
+        hipLaunchKernelGGL(bn_finalize_direct_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stats_partial, rpg, G, C, (double)count_per_group,
+                           gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, bn);
+        BDN_CHECK_LAUNCH("bn_finalize_direct");
+        return BDN_OK;
+    }
     const RowPlan p = row_plan(rpg);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64, G, p.RS), dim3(256), 0, st, stats_partial, rpg, p.rps, p.RS, C, (double*)ws);
     BDN_CHECK_LAUNCH("bn_reduce_rows");
