@@ -49,8 +49,9 @@ class GradBucketer:
     keys_no_reduce: gradients that are identically zero on every rank (conv biases in front of a
     BatchNorm) -- they sit at the tail of the layout and are never communicated."""
 
-    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=()):
+    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=(), enabled=True):
         self.layout, self.flat, self.group = layout, flat_grads, group
+        self.enabled = enabled                      # False: purely local step even inside an initialised process group
         skip = set(keys_no_reduce)
         keys = [k for k in layout.order if k not in skip]
         assert keys == layout.order[:len(keys)], 'non-reduced gradients must form the tail of the layout'
@@ -80,6 +81,8 @@ class GradBucketer:
         self.launched = [False] * len(self.buckets)
 
     def world_size(self):
+        if not self.enabled:
+            return 1
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def on_ready(self, keys):

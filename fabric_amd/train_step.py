@@ -20,11 +20,12 @@ from .parallel import FlatLayout, GradBucketer
 
 class TrainStep:
     def __init__(self, model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, eps=1e-7,
-                 process_group=None, n_buckets=4):
+                 process_group=None, n_buckets=4, distributed=True):
         self.model, self.lr = model, lr
         self.alpha, self.beta, self.eps = tversky_alpha, tversky_beta, eps
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = (dist.get_world_size(process_group)
+                      if distributed and dist.is_available() and dist.is_initialized() else 1)
         named = list(model.named_parameters())
         dev = named[0][1].device
         if dev.type != 'cuda':
@@ -40,7 +41,8 @@ class TrainStep:
             p.grad = self.layout.view(self.flat_grads, k)
         self.grads = {k: self.layout.view(self.flat_grads, k) for k, _ in named}
         bias_tail = [k for k in order if k.endswith('.bias') and k.split('.')[-2] in ('0', '3')]
-        self.bucketer = GradBucketer(self.layout, self.flat_grads, n_buckets, process_group, keys_no_reduce=bias_tail)
+        self.bucketer = GradBucketer(self.layout, self.flat_grads, n_buckets, process_group, keys_no_reduce=bias_tail,
+                                     enabled=self.world > 1)
         if self.world > 1:                                   # identical start on every rank (DataParallel broadcasts)
             dist.broadcast(self.flat_params, src=0, group=process_group)
         self._tv = None
