@@ -1,0 +1,102 @@
+// libbidate_hip: full-scene sliding-window inference helpers.
+// The two dates of a scene stay resident in HBM as band planes; tiles are gathered straight into the packed
+// NHWC batch and predictions are written straight into the scene mask -- no host-side patch stack.
+#include "common.hpp"
+
+static inline unsigned grid_for(size_t n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// ============================================================ gather_tiles
+// reference: utils/inference.py:134-184 (_get_patches) + :61-66 (NHWC->NCHW transpose) + train.py:190-193
+// (batch slice, host->device).  scene_d*: [C][H][W] f32 band planes.  origins: int32 [n][2] = (y0, x0).
+// out: [2n][p][p][Cpad] T, date-1 tiles first (the layout bdn_pack_input produces).
+// One thread per (tile pixel, 16-byte unit): plane reads are coalesced along x, every store is 16 bytes.
+template <typename T>
+__global__ void gather_tiles_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
+                                    const int* __restrict__ origins, T* __restrict__ out,
+                                    int n, int C, int H, int W, int p, int Cpad) {
+    constexpr int EPU = ET<T>::EPU;
+    const int upp = Cpad / EPU;
+    const size_t total = (size_t)2 * n * p * p * upp;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // unit index is the SLOW coordinate inside a tile row so that a wave reads 64 consecutive x of one plane set
+    const int x = i % p; size_t t = i / p;
+    const int u = t % upp; t /= upp;
+    const int y = t % p; const int tile = t / p;
+    const int date = tile >= n, tt = tile - date * n;
+    const int y0 = origins[2 * tt], x0 = origins[2 * tt + 1];
+    const size_t hw = (size_t)H * W;
+    const float* src = (date ? s2 : s1) + (size_t)(y0 + y) * W + (x0 + x);
+    float f[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; e++) {
+        const int c = u * EPU + e;
+        f[e] = c < C ? src[(size_t)c * hw] : 0.f;
+    }
+    T* dst = out + (((size_t)tile * p + y) * p + x) * Cpad + u * EPU;
+    *reinterpret_cast<uint4*>(dst) = Unit<T>::pack(f);
+}
+
+extern "C" int bdn_gather_tiles(int dtype, const float* scene_d1, const float* scene_d2, const int32_t* origins,
+                                void* out, int n_tiles, int C, int H, int W, int p, int Cpad, void* stream) {
+    if (!scene_d1 || !scene_d2 || !origins || !out) BDN_FAIL(BDN_E_ARG, "gather_tiles: null pointer");
+    if (n_tiles <= 0 || C <= 0 || p <= 0 || H < p || W < p || Cpad < C || Cpad % 16)
+        BDN_FAIL(BDN_E_SHAPE, "gather_tiles: need H,W >= p, Cpad a multiple of 16 and >= C");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BDN_BF16) {
+        const size_t total = (size_t)2 * n_tiles * p * p * (Cpad / 8);
+        hipLaunchKernelGGL(gather_tiles_kernel<bf16s>, dim3(grid_for(total)), dim3(256), 0, st,
+                           scene_d1, scene_d2, origins, (bf16s*)out, n_tiles, C, H, W, p, Cpad);
+    } else if (dtype == BDN_F32) {
+        const size_t total = (size_t)2 * n_tiles * p * p * (Cpad / 4);
+        hipLaunchKernelGGL(gather_tiles_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st,
+                           scene_d1, scene_d2, origins, (float*)out, n_tiles, C, H, W, p, Cpad);
+    } else BDN_FAIL(BDN_E_ARG, "gather_tiles: bad dtype");
+    BDN_CHECK_LAUNCH("gather_tiles");
+    return BDN_OK;
+}
+
+// ============================================================ argmax (+ stitch)
+// reference: `_, cd_preds = torch.max(preds, 1)` train.py:199 (first maximum wins ties), then
+// utils/inference.py:187-236 (_get_bands): main tiles, then last-column tiles, then last-row tiles, then the
+// corner are pasted in that order, later pastes overwriting earlier ones.  Equivalent order-free rule used here:
+// a pixel belongs to the far-edge band(s) it lies in (y >= H-p, x >= W-p) and only a tile anchored on exactly
+// those bands writes it, so tiles of one launch never race with different values.
+__global__ void argmax_stitch_kernel(const float* __restrict__ logits, const int* __restrict__ origins,
+                                     unsigned char* __restrict__ out, int n, int ncls, int p, int H, int W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pp = (size_t)p * p;
+    if (i >= (size_t)n * pp) return;
+    const int tile = i / pp; const int rem = i % pp;
+    const float* l = logits + (size_t)tile * ncls * pp + rem;
+    float best = l[0]; int arg = 0;
+    for (int c = 1; c < ncls; c++) {
+        const float v = l[(size_t)c * pp];
+        if (v > best) { best = v; arg = c; }
+    }
+    if (!origins) { out[i] = (unsigned char)arg; return; }
+    const int y0 = origins[2 * tile], x0 = origins[2 * tile + 1];
+    const int y = y0 + rem / p, x = x0 + rem % p;
+    const bool ty = y0 == H - p, tx = x0 == W - p;
+    const bool py = y >= H - p, px = x >= W - p;
+    if (ty == py && tx == px) out[(size_t)y * W + x] = (unsigned char)arg;
+}
+
+extern "C" int bdn_argmax(const float* logits, uint8_t* out, int n, int ncls, int H, int W, void* stream) {
+    if (!logits || !out) BDN_FAIL(BDN_E_ARG, "argmax: null pointer");
+    if (n <= 0 || ncls <= 0 || ncls > 256 || H <= 0 || W <= 0 || H != W) BDN_FAIL(BDN_E_SHAPE, "argmax: bad shape (square patches, <= 256 classes)");
+    hipLaunchKernelGGL(argmax_stitch_kernel, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       logits, (const int*)nullptr, out, n, ncls, H, H, W);
+    BDN_CHECK_LAUNCH("argmax");
+    return BDN_OK;
+}
+
+extern "C" int bdn_argmax_stitch(const float* logits, const int32_t* origins, uint8_t* mask,
+                                 int n_tiles, int ncls, int p, int H, int W, void* stream) {
+    if (!logits || !origins || !mask) BDN_FAIL(BDN_E_ARG, "argmax_stitch: null pointer");
+    if (n_tiles <= 0 || ncls <= 0 || ncls > 256 || p <= 0 || H < p || W < p) BDN_FAIL(BDN_E_SHAPE, "argmax_stitch: bad shape");
+    hipLaunchKernelGGL(argmax_stitch_kernel, dim3(grid_for((size_t)n_tiles * p * p)), dim3(256), 0, (hipStream_t)stream,
+                       logits, origins, mask, n_tiles, ncls, p, H, W);
+    BDN_CHECK_LAUNCH("argmax_stitch");
+    return BDN_OK;
+}

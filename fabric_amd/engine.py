@@ -231,7 +231,7 @@ class BiDateEngine:
     def invalidate_weights(self):
         self._packed_valid = False
 
-    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st):
+    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st, reuse_eval_bn=False):
         hk, wk = ws.dims[L.level - 1]
         wf, _ = self._weights(L, P, False)
         z = ws.z[L.name]
@@ -247,7 +247,7 @@ class BiDateEngine:
                  ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']), BN_EPS, BN_MOMENTUM,
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']),
                  ptr(P[f'{L.bn}.num_batches_tracked']), ptr(bn), ptr(ws.bnws), st)
-        else:
+        elif not reuse_eval_bn:
             call('bdn_bn_eval', ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']),
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']), BN_EPS, G, L.cout, ptr(bn), st)
         return z, bn
@@ -264,13 +264,39 @@ class BiDateEngine:
         x_d1 = x_d1.contiguous().float()
         x_d2 = x_d2.contiguous().float()
         B, C, H, W = x_d1.shape
-        dev = x_d1.device
-        ws = self.workspace(B, H, W, dev)
+        ws = self.workspace(B, H, W, x_d1.device)
+        call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, _lib.stream_ptr())
+        return self._forward_packed(ws, P, training), ws
+
+    def forward_tiles(self, scene_d1, scene_d2, origins, P, patch_size, reuse_eval_bn=False):
+        """Eval-mode forward of the tiles at `origins` (device int32 [n,2] = (y0,x0)) of a scene whose two dates
+        are resident as [C,H,W] float32 band planes (train.py:190-197 without the host-side patch stack).
+        reuse_eval_bn: the BatchNorm tables of this workspace are already those of P's running statistics.
+        Returns (logits [n,n_classes,p,p] float32, workspace)."""
+        if not (scene_d1.is_cuda and scene_d2.is_cuda and origins.is_cuda):
+            raise RuntimeError('fabric_amd: scene planes and tile origins must be CUDA/HIP tensors -- there is no CPU path')
+        if scene_d1.shape != scene_d2.shape or scene_d1.dim() != 3 or scene_d1.shape[0] != self.n_channels:
+            raise RuntimeError(f'expected two [{self.n_channels},H,W] scenes, got {tuple(scene_d1.shape)} and {tuple(scene_d2.shape)}')
+        if scene_d1.dtype != torch.float32 or scene_d2.dtype != torch.float32 or origins.dtype != torch.int32:
+            raise RuntimeError('scene planes must be float32 and origins int32')
+        if not (scene_d1.is_contiguous() and scene_d2.is_contiguous() and origins.is_contiguous()):
+            raise RuntimeError('scene planes and origins must be contiguous')
+        C, H, W = scene_d1.shape
+        n, p = origins.shape[0], patch_size
+        ws = self.workspace(n, p, p, scene_d1.device)
+        call('bdn_gather_tiles', self.dt, ptr(scene_d1), ptr(scene_d2), ptr(origins), ptr(ws.x0),
+             n, C, H, W, p, self.cp, _lib.stream_ptr())
+        return self._forward_packed(ws, P, False, reuse_eval_bn), ws
+
+    def _forward_packed(self, ws, P, training, reuse_eval_bn=False):
+        """The network on the packed input already in ws.x0."""
+        B, H, W = ws.B, ws.H, ws.W
+        dev = ws.x0.device
         st = _lib.stream_ptr()
         by = {L.name: L for L in self.layers}
         if self._packed_valid and self._packed_versions != tuple(P[f'{L.conv}.weight']._version for L in self.layers):
             self._packed_valid = False            # an optimizer touched the master weights
-        call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, st)
+        rb = reuse_eval_bn and not training
         # ---- shared encoder on both dates (2B images, 2 statistic groups)
         for k in range(1, 6):
             hk, wk = ws.dims[k - 1]
@@ -282,8 +308,8 @@ class BiDateEngine:
                 call('bdn_bnrelu_pool', self.dt, ptr(ws.z[f'e{k - 1}b']), ptr(ws.bn[f'e{k - 1}b']), B,
                      ptr(ws.pool[k]), 2 * B, hp, wp, ENC_CH[k - 2], st)
                 src = ws.pool[k]
-            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st)
-            zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st)
+            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb)
+            zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st, rb)
             call('bdn_fuse_product', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], st)
         # ---- decoder on the fused skips
         prev, prev_bn, prev_mode, cprev = ws.f[5], None, IN_PLAIN, ENC_CH[4]
@@ -294,13 +320,13 @@ class BiDateEngine:
             La, Lb = by[f'd{j}a'], by[f'd{j}b']
             call('bdn_upsample2x', self.dt, ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.U[j]),
                  B, hs, wsrc, hk, wk, cprev, st)
-            za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st)
-            zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st)
+            za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st, rb)
+            zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st, rb)
             prev, prev_bn, prev_mode, cprev = zb, bnb, IN_BNRELU, Lb.cout
         logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)
         call('bdn_outc_fwd', self.dt, ptr(prev), ptr(prev_bn), ptr(P['outc.conv.weight']), ptr(P['outc.conv.bias']),
              ptr(logits), B, H, W, cprev, self.n_classes, st)
-        return logits, ws
+        return logits
 
     # ------------------------------------------------------------------ backward
     def backward(self, ws, dlogits, P, grads, on_ready=None, zero_bias_grads=True, wgrad_stream=True):

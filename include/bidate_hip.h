@@ -143,6 +143,20 @@ int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float b
                 float* ws, float* loss, int32_t* counts, float* dlogits,
                 int B, int ncls, int H, int W, void* stream);
 
+/* ---- full-scene sliding-window inference: train.py:182-205, utils/inference.py:134-236 ----
+ * The scene stays in HBM as band planes scene_d*: [C][H][W] f32.  origins: device int32 [n_tiles][2] = (y0, x0)
+ * in the reference's tile order (utils/inference.py:160-184: hs*ws main tiles, lc last-column tiles, lr last-row
+ * tiles, corner).  out: [2*n_tiles][p][p][Cpad] packed batch (date-1 tiles first) = the encoder input. */
+int bdn_gather_tiles(int dtype, const float* scene_d1, const float* scene_d2, const int32_t* origins,
+                     void* out, int n_tiles, int C, int H, int W, int p, int Cpad, void* stream);
+/* `_, cd_preds = torch.max(preds, 1)` (train.py:199; first maximum wins): logits [n][ncls][H][W] f32 -> uint8 [n][H][W]
+ * (square patches only). */
+int bdn_argmax(const float* logits, uint8_t* out, int n, int ncls, int H, int W, void* stream);
+/* argmax + _get_bands (utils/inference.py:187-236): class index of every tile pixel written to mask [H][W] uint8 at
+ * the tile origin; far-edge tiles own the far-edge bands exactly as the reference's paste order leaves them. */
+int bdn_argmax_stitch(const float* logits, const int32_t* origins, uint8_t* mask,
+                      int n_tiles, int ncls, int p, int H, int W, void* stream);
+
 /* ---- optim.SGD(lr) step, train.py:55,95: p -= lr * grad_scale * g over a flat f32 buffer ---- */
 int bdn_sgd_step(float* params, const float* grads, float lr, float grad_scale, size_t n, void* stream);
 

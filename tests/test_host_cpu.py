@@ -143,3 +143,29 @@ def test_grad_bucketer_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
     assert all('ok' in o for o in outs)
+
+
+def test_inference_tiler_matches_golden(golden_dir):
+    """fabric_amd.utils.inference._get_patches/_get_bands vs fixture G7 (captured from the reference's
+    utils/inference.py:134-236) and vs the oracle on ragged / exact-multiple scene sizes."""
+    from fabric_amd.utils import inference as inf
+    from oracle import bidate_oracle as O
+    g = np.load(os.path.join(golden_dir, 'g7_tiling.npz'))
+    hs, ws, lc, lr, h, w = [int(v) for v in g['meta']]
+    r = np.random.default_rng(7)          # same generator state as oracle/make_golden.py before the tiling case
+    r.standard_normal((2, 3, 40, 36)); r.uniform(0, 1, (40, 36)); r.standard_normal((2, 3, 30, 50)); r.uniform(0, 1, (30, 50))
+    arr = r.standard_normal((300, 260, 13)).astype(np.float32)
+    tiles, hs2, ws2, lc2, lr2, h2, w2 = inf._get_patches(arr, patch_dim=128)
+    assert (hs2, ws2, lc2, lr2, h2, w2) == (hs, ws, lc, lr, h, w)
+    assert np.allclose(tiles.reshape(9, -1).astype(np.float64).sum(1), g['tile_checksums'])
+    img = inf._get_bands(g['pred'].astype(np.float64), hs, ws, lc, lr, h, w, patch_size=128)
+    assert img.dtype == np.float64 and np.array_equal(img.astype(np.uint8), g['stitched'])
+    for (hh, ww, p) in [(70, 33, 16), (64, 96, 32), (40, 40, 40), (129, 257, 128)]:
+        a = r.standard_normal((hh, ww, 4)).astype(np.float32)
+        t, *meta = inf._get_patches(a, p)
+        to, *metao = O.tile_scene(a, p)
+        assert np.array_equal(t, to) and tuple(meta) == tuple(metao)
+        pred = r.integers(0, 2, (t.shape[0], p, p)).astype(np.float64)
+        assert np.array_equal(inf._get_bands(pred, *meta, patch_size=p), O.stitch_scene(pred, *metao, p))
+    with pytest.raises(ValueError):
+        inf.tile_origins(100, 300, 128)
