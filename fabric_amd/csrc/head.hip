@@ -241,7 +241,7 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
 template <int NC>
 __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
                                     float* __restrict__ sums, int32_t* __restrict__ counts, int B, int ncls, int H, int W,
-                                    int rows_per_block) {
+                                    int rows_per_block, int We) {
     // block = 256 threads = RL row lanes x CW columns (CW = min(W rounded up to a power of two, 256));
     // grid.x = column blocks, grid.y = row blocks
     extern __shared__ float sm[];                         // [RL][3*NC][CW]
@@ -280,14 +280,28 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
         sm[(rl * 3 * NC + 2 * NC + k) * CW + cl] = fn[k];
     }
     __syncthreads();
-    if (rl == 0 && x < W)
-        for (int k = 0; k < ncls; k++)
+    if (We == W) {
+        if (rl == 0 && x < W)
+            for (int k = 0; k < ncls; k++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float v = 0.f;
-                for (int r = 0; r < RL; r++) v += sm[(r * 3 * NC + j * NC + k) * CW + cl];
-                atomicAdd(&sums[(j * ncls + k) * W + x], v);
+                for (int j = 0; j < 3; j++) {
+                    float v = 0.f;
+                    for (int r = 0; r < RL; r++) v += sm[(r * 3 * NC + j * NC + k) * CW + cl];
+                    atomicAdd(&sums[(j * ncls + k) * W + x], v);
+                }
+    } else {
+        // [B,1,H,W] labels: the reference reduces over the columns too (dims == (0,2,3)); one atomic per block and address
+        const int tid = rl + RL * cl;
+        if (tid < 3 * NC) {
+            float v = 0.f;
+            for (int i = 0; i < RL * CW; i++) {
+                const int r = i / CW, c = i % CW;
+                if (blockIdx.x * CW + c < W) v += sm[(r * 3 * NC + tid) * CW + c];
             }
+            const int j = tid / NC, k = tid % NC;
+            if (k < ncls) atomicAdd(&sums[j * ncls + k], v);
+        }
+    }
     if (counts) {
         int* ism = reinterpret_cast<int*>(sm);
         __syncthreads();
@@ -299,7 +313,7 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
 }
 
 // loss = 1 - mean_{c,w} TP/(TP + a FP + b FN + eps).  Overwrites sums[0] with 1/D and sums[1] with TP/D^2.
-__global__ void tversky_finish_kernel(float* __restrict__ sums, float alpha, float beta, float eps, int ncls, int W, float* __restrict__ loss) {
+__global__ void tversky_finish_kernel(float* __restrict__ sums, float alpha, float beta, float eps, int ncls, int W, float* __restrict__ loss) {   // W = effective width (1 when the columns are reduced too)
     __shared__ double red[256];
     double acc = 0.0;
     const int n = ncls * W;
@@ -316,11 +330,11 @@ __global__ void tversky_finish_kernel(float* __restrict__ sums, float alpha, flo
 
 __global__ void tversky_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
                                    const float* __restrict__ coef, float alpha, float beta, float* __restrict__ dlogits,
-                                   int B, int ncls, int H, int W) {
-    const size_t hw = (size_t)H * W, npix = (size_t)B * hw;
+                                   int B, int ncls, int H, int Wimg, int W) {
+    const size_t hw = (size_t)H * Wimg, npix = (size_t)B * hw;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    const size_t b = p / hw, q = p % hw; const int x = q % W;
+    const size_t b = p / hw, q = p % hw; const int x = W == 1 ? 0 : (int)(q % Wimg);
     const int n = ncls * W;
     float l[OUTC_MAXCLS], dp[OUTC_MAXCLS]; float m = -INFINITY;
 #pragma unroll
@@ -344,27 +358,112 @@ __global__ void tversky_bwd_kernel(const float* __restrict__ logits, const uint8
     for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) dlogits[(b * ncls + k) * hw + q] = l[k] * (dp[k] - dot);
 }
 
-extern "C" int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
-                           float* ws, float* loss, int32_t* counts, float* dlogits,
-                           int B, int ncls, int H, int W, void* stream) {
-    if (!logits || !labels || !ws || !loss) BDN_FAIL(BDN_E_ARG, "tversky: null pointer");
-    if (ncls < 2 || ncls > OUTC_MAXCLS) BDN_FAIL(BDN_E_SHAPE, "tversky: ncls=%d unsupported (2..%d)", ncls, OUTC_MAXCLS);
+extern "C" int bdn_overlap_loss(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
+                                int reduce_w, float* ws, float* loss, int32_t* counts, float* dlogits,
+                                int B, int ncls, int H, int W, void* stream) {
+    if (!logits || !labels || !ws || !loss) BDN_FAIL(BDN_E_ARG, "overlap_loss: null pointer");
+    if (ncls < 2 || ncls > OUTC_MAXCLS) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: ncls=%d unsupported (2..%d)", ncls, OUTC_MAXCLS);
+    if (B <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * W, st);
+    const int We = reduce_w ? 1 : W;
+    hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * We, st);
     if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
     int CW = 1; while (CW < W && CW < 256) CW *= 2;
     const int RL = 256 / CW, rows = B * H;
     int rpb = (rows + 255) / 256; if (rpb < RL) rpb = RL;                       // ~256 row blocks
     dim3 grid((W + CW - 1) / CW, (rows + rpb - 1) / rpb), block(RL, CW);
-    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, ws, counts, B, ncls, H, W, rpb);
-    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, ws, counts, B, ncls, H, W, rpb);
+    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, ws, counts, B, ncls, H, W, rpb, We);
+    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, ws, counts, B, ncls, H, W, rpb, We);
     BDN_CHECK_LAUNCH("tversky_sums");
-    hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(256), 0, st, ws, alpha, beta, eps, ncls, W, loss);
+    hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(256), 0, st, ws, alpha, beta, eps, ncls, We, loss);
     BDN_CHECK_LAUNCH("tversky_finish");
     if (dlogits) {
-        hipLaunchKernelGGL(tversky_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, logits, labels, ws, alpha, beta, dlogits, B, ncls, H, W);
+        hipLaunchKernelGGL(tversky_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, logits, labels, ws, alpha, beta, dlogits, B, ncls, H, W, We);
         BDN_CHECK_LAUNCH("tversky_bwd");
     }
+    return BDN_OK;
+}
+
+extern "C" int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
+                           float* ws, float* loss, int32_t* counts, float* dlogits,
+                           int B, int ncls, int H, int W, void* stream) {
+    return bdn_overlap_loss(logits, labels, alpha, beta, eps, 0, ws, loss, counts, dlogits, B, ncls, H, W, stream);
+}
+
+// ============================================================ Focal loss (utils/metrics.py:8-48)
+// loss_i = -(1 - pt)^gamma * a[t] * log pt with pt = softmax(l)[t]; the modulating factor is built from
+// `logpt.data.exp()` (:35) and is therefore a constant for the gradient:
+//   d loss_i / d l_k = -(1 - pt)^gamma * a[t] * ([k == t] - p_k)   (times 1/N when size_average).
+// pass 1: per-pixel loss + dlogits, per-block partial sums (double) -> ws;  pass 2: fixed-order finish.
+__global__ void focal_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                             const float* __restrict__ alpha, float gamma, float gscale,
+                             double* __restrict__ part, int32_t* __restrict__ counts, float* __restrict__ dlogits,
+                             int B, int ncls, size_t hw) {
+    __shared__ double red[256];
+    __shared__ int ired[256 * 4];
+    const size_t npix = (size_t)B * hw;
+    double acc = 0.0;
+    int c_tp = 0, c_fp = 0, c_fn = 0, c_ok = 0;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+        const size_t b = p / hw, q = p % hw;
+        float l[OUTC_MAXCLS]; float m = -INFINITY; int am = 0;
+#pragma unroll
+        for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) { l[k] = logits[(b * ncls + k) * hw + q]; if (l[k] > m) { m = l[k]; am = k; } }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) den += expf(l[k] - m);
+        const int t = labels[p];
+        const float lse = m + logf(den);
+        float lt = 0.f;
+#pragma unroll
+        for (int k = 0; k < OUTC_MAXCLS; k++) if (k == t) lt = l[k];
+        const float logpt = lt - lse, pt = expf(logpt);
+        const float a = alpha ? alpha[t] : 1.f;
+        const float mod = gamma == 0.f ? 1.f : powf(fmaxf(1.f - pt, 0.f), gamma);
+        acc += (double)(-mod * a * logpt);
+        if (dlogits) {
+            const float c = -mod * a * gscale;
+#pragma unroll
+            for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls)
+                dlogits[(b * ncls + k) * hw + q] = c * ((k == t ? 1.f : 0.f) - expf(l[k] - lse));
+        }
+        c_tp += (am == 1 && t == 1); c_fp += (am == 1 && t != 1); c_fn += (am != 1 && t == 1); c_ok += (am == t);
+    }
+    red[threadIdx.x] = acc;
+    ired[threadIdx.x * 4 + 0] = c_tp; ired[threadIdx.x * 4 + 1] = c_fp; ired[threadIdx.x * 4 + 2] = c_fn; ired[threadIdx.x * 4 + 3] = c_ok;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+    if (counts && threadIdx.x < 4) { int v = 0; for (int i = 0; i < 256; i++) v += ired[i * 4 + threadIdx.x]; atomicAdd(&counts[threadIdx.x], v); }
+}
+
+__global__ void focal_finish_kernel(const double* __restrict__ part, int nblk, double scale, float* __restrict__ loss) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += part[i];
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * scale);
+}
+
+extern "C" size_t bdn_focal_workspace_bytes(void) { return sizeof(double) * 1024; }
+
+extern "C" int bdn_focal(const float* logits, const uint8_t* labels, float gamma, const float* alpha, int size_average,
+                         void* ws, float* loss, int32_t* counts, float* dlogits,
+                         int B, int ncls, int H, int W, void* stream) {
+    if (!logits || !labels || !ws || !loss) BDN_FAIL(BDN_E_ARG, "focal: null pointer");
+    if (ncls < 2 || ncls > OUTC_MAXCLS) BDN_FAIL(BDN_E_SHAPE, "focal: ncls=%d unsupported (2..%d)", ncls, OUTC_MAXCLS);
+    if (B <= 0 || H <= 0 || W <= 0 || gamma < 0.f) BDN_FAIL(BDN_E_SHAPE, "focal: bad shape or negative gamma");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    int nblk = (int)((npix + 255) / 256); if (nblk > 1024) nblk = 1024;
+    if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
+    const double inv = size_average ? 1.0 / (double)npix : 1.0;
+    hipLaunchKernelGGL(focal_kernel, dim3(nblk), dim3(256), 0, st, logits, labels, alpha, gamma, (float)inv,
+                       (double*)ws, counts, dlogits, B, ncls, (size_t)H * W);
+    BDN_CHECK_LAUNCH("focal");
+    hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblk, inv, loss);
+    BDN_CHECK_LAUNCH("focal_finish");
     return BDN_OK;
 }
 

@@ -3,7 +3,7 @@ train step needs: running-mean metric dicts, criterion factory, model factory.""
 import numpy as np
 
 from ..models.bidate_model import BiDateNet
-from .metrics import TverskyLoss
+from .metrics import FocalLoss, TverskyLoss, dice_loss, jaccard_loss
 
 
 def initialize_metrics():
@@ -27,12 +27,19 @@ def set_metrics(metric_dict, cd_loss, cd_corrects, cd_report):
 
 
 def get_criterion(opt):
-    """reference utils/helpers.py:288-314.  Only the default criterion (tversky, metadata.json:41) is on the
-    built path; the reference's bce/focal options do not run as shipped."""
+    """reference utils/helpers.py:288-314.  `focal` reads opt.focal_gamma exactly like the reference (absent from
+    metadata.json there, so it raises AttributeError unless the caller adds it); `bce` cannot run on BiDateNet's
+    [B,2,H,W] logits with [B,H,W] labels in the reference either (shape mismatch inside BCEWithLogitsLoss)."""
+    if opt.loss_function == 'focal':
+        return FocalLoss(opt.focal_gamma)
+    if opt.loss_function == 'dice':
+        return dice_loss
+    if opt.loss_function == 'jaccard':
+        return jaccard_loss
     if opt.loss_function == 'tversky':
         return TverskyLoss(alpha=opt.tversky_alpha, beta=opt.tversky_beta)
-    raise NotImplementedError(f'fabric_amd: loss_function={opt.loss_function!r} is outside the built hot path '
-                              f'(SURVEY.md section 8f, "next")')
+    raise NotImplementedError(f'fabric_amd: loss_function={opt.loss_function!r}: the reference\'s BCEWithLogitsLoss '
+                              f'branch fails on [B,2,H,W] logits vs [B,H,W] labels and is not built')
 
 
 def load_model(opt, device, precision=None):

@@ -143,6 +143,25 @@ int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float b
                 float* ws, float* loss, int32_t* counts, float* dlogits,
                 int B, int ncls, int H, int W, void* stream);
 
+/* ---- dice_loss / jaccard_loss / TverskyLoss in either label rank, utils/metrics.py:51-171 ----
+ * One ratio TP / (TP + alpha FP + beta FN + eps) per reduction cell, averaged:
+ *   TverskyLoss(alpha, beta, eps) as is;  jaccard_loss(eps) = (1, 1, eps);  dice_loss(eps) = (0.5, 0.5, eps / 2)
+ *   (2I / (2I + FP + FN + eps), utils/metrics.py:80-83).
+ * reduce_w = 0: [B,H,W] labels, reference dims == (0,2): one cell per (class, column);
+ * reduce_w = 1: [B,1,H,W] labels, dims == (0,2,3): one cell per class.  Other arguments as bdn_tversky. */
+int bdn_overlap_loss(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
+                     int reduce_w, float* ws, float* loss, int32_t* counts, float* dlogits,
+                     int B, int ncls, int H, int W, void* stream);
+
+/* ---- FocalLoss(gamma, alpha, size_average).forward, utils/metrics.py:8-48 (criterion 'focal', utils/helpers.py:305) ----
+ * labels uint8 [B,H,W] (or [B,1,H,W], same memory).  alpha: NULL or f32[ncls] class weights (device).
+ * The modulating factor (1-pt)^gamma is a constant for the gradient exactly as in the reference (:35).
+ * ws: bdn_focal_workspace_bytes() bytes.  loss, counts, dlogits as bdn_tversky. */
+size_t bdn_focal_workspace_bytes(void);
+int bdn_focal(const float* logits, const uint8_t* labels, float gamma, const float* alpha, int size_average,
+              void* ws, float* loss, int32_t* counts, float* dlogits,
+              int B, int ncls, int H, int W, void* stream);
+
 /* ---- full-scene sliding-window inference: train.py:182-205, utils/inference.py:134-236 ----
  * The scene stays in HBM as band planes scene_d*: [C][H][W] f32.  origins: device int32 [n_tiles][2] = (y0, x0)
  * in the reference's tile order (utils/inference.py:160-184: hs*ws main tiles, lc last-column tiles, lr last-row

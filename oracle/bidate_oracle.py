@@ -251,6 +251,22 @@ def jaccard_loss(logits, true, eps=1e-7):
     return 1 - (inter / (card - inter + eps)).mean()
 
 
+def focal_loss(logits, true, gamma=0.0, alpha=None, size_average=True):
+    """FocalLoss.forward -- utils/metrics.py:8-48.  The modulating factor (1-pt)**gamma is built from
+    `logpt.data.exp()` (:35), i.e. it is a CONSTANT for autograd: d loss / d logits has no gamma*(1-pt)**(gamma-1)
+    term.  alpha: None, a float a (-> class weights [a, 1-a], :13-14) or a list of class weights (:15-16)."""
+    nc = logits.shape[1]
+    x = logits.reshape(logits.shape[0], nc, -1).transpose(1, 2).reshape(-1, nc)     # :20-28
+    t = true.reshape(-1, 1).long()
+    logpt = torch.log_softmax(x, dim=1).gather(1, t).view(-1)                       # :32-34
+    pt = logpt.detach().exp()
+    if alpha is not None:
+        a = torch.tensor([alpha, 1 - alpha]) if isinstance(alpha, (float, int)) else torch.tensor(alpha)
+        logpt = logpt * a.to(x.dtype).gather(0, t.view(-1))                         # :37-41
+    loss = -1 * (1 - pt) ** gamma * logpt
+    return loss.mean() if size_average else loss.sum()
+
+
 # --------------------------------------------------------------------------
 # train step -- train.py:83-101 with optim.SGD(lr) from train.py:55
 # --------------------------------------------------------------------------

@@ -179,6 +179,52 @@ def _loader_case(ref_dl, ref_inf, oracle):
     print('g7 loader/tiling ok')
 
 
+def _loss_case_more(ref_metrics, oracle):
+    """G9: focal loss (all constructor forms) and the gradients of dice / jaccard / tversky in both label ranks,
+    on 2-class and 5-class logits."""
+    import warnings
+    warnings.filterwarnings('ignore')            # the reference calls F.log_softmax without dim
+    r = np.random.default_rng(9)
+    out = {}
+    for tag, nc, shape in (('c2', 2, (3, 24, 20)), ('c5', 5, (2, 16, 12))):
+        logits = torch.from_numpy((2.0 * r.standard_normal((shape[0], nc) + shape[1:])).astype(np.float32))
+        lbl3 = torch.from_numpy(r.integers(0, nc, shape).astype(np.int64))
+        out[f'{tag}/logits'], out[f'{tag}/labels'] = logits.numpy(), lbl3.numpy().astype(np.uint8)
+        forms = [('g0', dict(gamma=0)), ('g2', dict(gamma=2)), ('g1.5_sum', dict(gamma=1.5, size_average=False))]
+        if nc == 2:
+            forms += [('g2_a0.25', dict(gamma=2, alpha=0.25))]
+        else:
+            forms += [('g2_alist', dict(gamma=2, alpha=[0.1, 0.2, 0.3, 0.15, 0.25]))]
+        for name, kw in forms:
+            lg = logits.clone().requires_grad_(True)
+            v = ref_metrics.FocalLoss(**kw)(lg, lbl3)
+            v.backward()
+            lo = logits.clone().requires_grad_(True)
+            vo = oracle.focal_loss(lo, lbl3, **kw)
+            vo.backward()
+            assert abs(float(vo) - float(v)) < 1e-5 * max(1.0, abs(float(v))), (name, float(vo), float(v))
+            assert float((lo.grad - lg.grad).abs().max()) < 1e-6 * max(1.0, float(lg.grad.abs().max()))
+            out[f'{tag}/focal_{name}'] = np.float64(v.item())
+            out[f'{tag}/dfocal_{name}'] = lg.grad.numpy()
+        for rank, lbl in (('r3', lbl3), ('r4', lbl3[:, None])):
+            for name, fn, ofn in (('dice', ref_metrics.dice_loss, oracle.dice_loss),
+                                  ('jaccard', ref_metrics.jaccard_loss, oracle.jaccard_loss),
+                                  ('tversky_0.3_0.7', ref_metrics.TverskyLoss(alpha=0.3, beta=0.7),
+                                   lambda a, b: oracle.tversky_loss(a, b, 0.3, 0.7))):
+                lg = logits.clone().requires_grad_(True)
+                v = fn(lg, lbl)
+                v.backward()
+                lo = logits.clone().requires_grad_(True)
+                vo = ofn(lo, lbl)
+                vo.backward()
+                assert abs(float(vo) - float(v)) < 1e-6, (name, rank)
+                assert float((lo.grad - lg.grad).abs().max()) < 1e-7
+                out[f'{tag}/{name}_{rank}'] = np.float64(v.item())
+                out[f'{tag}/d{name}_{rank}'] = lg.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g9_losses_more.npz'), **out)
+    print('g9_losses_more:', {k: round(float(v), 6) for k, v in out.items() if np.ndim(v) == 0})
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import bidate_oracle as oracle
@@ -186,12 +232,17 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     BiDateNet, ref_metrics, ref_dl, ref_inf = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'losses':        # regenerate only the loss fixtures
+        _loss_case(ref_metrics, oracle)
+        _loss_case_more(ref_metrics, oracle)
+        return
     _train_case(BiDateNet, ref_metrics, oracle, filler, 'g1_c3_b4_s32', 3, 4, 32)
     _train_case(BiDateNet, ref_metrics, oracle, filler, 'g2_c13_b2_s128', 13, 2, 128)
     _train_case(BiDateNet, ref_metrics, oracle, filler, 'g4_c13_b2_s90', 13, 2, 90)
     _train_case(BiDateNet, ref_metrics, oracle, filler, 'g6_c3_b4_s32_diffdates', 3, 4, 32, different_dates=True)
     _train_case(BiDateNet, ref_metrics, oracle, filler, 'g8_c13_b3_h40_w72', 13, 3, 40, sw=72)
     _loss_case(ref_metrics, oracle)
+    _loss_case_more(ref_metrics, oracle)
     _loader_case(ref_dl, ref_inf, oracle)
 
 

@@ -103,3 +103,29 @@ def test_binary_prf_matches_sklearn():
         pred = (r.uniform(0, 1, 5000) < p_pos).astype(np.int64)
         ref = prfs(lab, pred, average='binary', pos_label=1, zero_division=0)[:3]
         assert np.allclose(O.binary_prf(torch.from_numpy(lab), torch.from_numpy(pred)), ref)
+
+
+def test_losses_more_match_golden(golden_dir):
+    """G9: focal (all constructor forms), dice / jaccard / tversky values and gradients in both label ranks."""
+    g = np.load(os.path.join(golden_dir, 'g9_losses_more.npz'))
+    for tag in ('c2', 'c5'):
+        logits = torch.from_numpy(g[f'{tag}/logits'])
+        lbl3 = torch.from_numpy(g[f'{tag}/labels'].astype(np.int64))
+        forms = [('g0', dict(gamma=0)), ('g2', dict(gamma=2)), ('g1.5_sum', dict(gamma=1.5, size_average=False))]
+        forms += [('g2_a0.25', dict(gamma=2, alpha=0.25))] if tag == 'c2' else \
+            [('g2_alist', dict(gamma=2, alpha=[0.1, 0.2, 0.3, 0.15, 0.25]))]
+        for name, kw in forms:
+            lg = logits.clone().requires_grad_(True)
+            v = O.focal_loss(lg, lbl3, **kw)
+            v.backward()
+            ref = float(g[f'{tag}/focal_{name}'])
+            assert abs(float(v) - ref) < 1e-5 * max(1.0, abs(ref))
+            assert np.abs(lg.grad.numpy() - g[f'{tag}/dfocal_{name}']).max() < 1e-6 * max(1.0, np.abs(g[f'{tag}/dfocal_{name}']).max())
+        for rank, lbl in (('r3', lbl3), ('r4', lbl3[:, None])):
+            for name, fn in (('dice', O.dice_loss), ('jaccard', O.jaccard_loss),
+                             ('tversky_0.3_0.7', lambda a, b: O.tversky_loss(a, b, 0.3, 0.7))):
+                lg = logits.clone().requires_grad_(True)
+                v = fn(lg, lbl)
+                v.backward()
+                assert abs(float(v) - float(g[f'{tag}/{name}_{rank}'])) < 1e-6
+                assert np.abs(lg.grad.numpy() - g[f'{tag}/d{name}_{rank}']).max() < 1e-7
