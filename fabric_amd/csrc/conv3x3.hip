@@ -180,14 +180,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         R##_00 = LDB(wb0 + o_, 0); if (KPS > 1) R##_01 = LDB(wb0 + o_, 1);                              \
         if (NJ > 1) { R##_10 = LDB(wb1 + o_, 0); if (KPS > 1) R##_11 = LDB(wb1 + o_, 1); }              \
     }
-#define MMA_KG(kg_, b0_, b1_)                                                                            \
+    // A fragments are double-buffered in registers (sets ae / ao, by parity of the k-group index q inside the
+    // chunk): the ds_reads of k-group q+1 are issued, and pinned, ahead of the MFMAs of k-group q, so their LDS
+    // latency hides behind 4-8 MFMAs instead of stalling the wave before every pair of MFMAs.
+    uint4 ae0, ae1, ae2, ae3, ao0, ao1, ao2, ao3;
+    ae0 = ae1 = ae2 = ae3 = ao0 = ao1 = ao2 = ao3 = make_uint4(0, 0, 0, 0);
+    static_assert(MI <= 4, "A fragment registers are named scalars");
+#define A_OFF(q_) ((((q_) / KG) / 3) * ROWP + (((q_) / KG) % 3) * PSTR + ((q_) % KG) * 32)
+#define LDSA(mi_, q_) (*reinterpret_cast<const uint4*>(pcur + a_off[mi_] + A_OFF(q_)))
+#define A_LOAD(S, q_)                                                                                    \
     {                                                                                                   \
-        uint4 af_[MI];                                                                                  \
-        _Pragma("unroll") for (int mi = 0; mi < MI; mi++)                                                \
-            af_[mi] = *reinterpret_cast<const uint4*>(pcur + a_off[mi] + tapoff + (kg_) * 32);           \
-        _Pragma("unroll") for (int mi = 0; mi < MI; mi++) {                                              \
-            Mma<T>::run(af_[mi], b0_, acc[mi][0]);                                                      \
-            if (NJ > 1) Mma<T>::run(af_[mi], b1_, acc[mi][NJ - 1]);                                     \
+        S##0 = LDSA(0, q_);                                                                             \
+        if (MI > 1) S##1 = LDSA(MI > 1 ? 1 : 0, q_);                                                    \
+        if (MI > 2) { S##2 = LDSA(MI > 2 ? 2 : 0, q_); S##3 = LDSA(MI > 2 ? 3 : 0, q_); }               \
+    }
+#define A_MMA(S, b0_, b1_)                                                                               \
+    {                                                                                                   \
+        Mma<T>::run(S##0, b0_, acc[0][0]); if (NJ > 1) Mma<T>::run(S##0, b1_, acc[0][NJ - 1]);          \
+        if (MI > 1) { Mma<T>::run(S##1, b0_, acc[MI > 1 ? 1 : 0][0]); if (NJ > 1) Mma<T>::run(S##1, b1_, acc[MI > 1 ? 1 : 0][NJ - 1]); } \
+        if (MI > 2) {                                                                                   \
+            Mma<T>::run(S##2, b0_, acc[MI > 2 ? 2 : 0][0]); if (NJ > 1) Mma<T>::run(S##2, b1_, acc[MI > 2 ? 2 : 0][NJ - 1]); \
+            Mma<T>::run(S##3, b0_, acc[MI > 2 ? 3 : 0][0]); if (NJ > 1) Mma<T>::run(S##3, b1_, acc[MI > 2 ? 3 : 0][NJ - 1]); \
+        }                                                                                               \
+    }
+    // k-group q of the chunk: prefetch q+1 into the other set (except after the last one), then the MFMAs of q
+#define KGSTEP(q_, b0_, b1_)                                                                             \
+    {                                                                                                   \
+        if constexpr ((((q_)) & 1) == 0) {                                                              \
+            if constexpr ((q_) + 1 < 9 * KG) { A_LOAD(ao, (q_) + 1) }                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            A_MMA(ae, b0_, b1_)                                                                         \
+        } else {                                                                                        \
+            if constexpr ((q_) + 1 < 9 * KG) { A_LOAD(ae, (q_) + 1) }                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            A_MMA(ao, b0_, b1_)                                                                         \
         }                                                                                               \
     }
     // one step: RC holds this step's filters, RN receives those of step st_+2 (wrapping into the next chunk).
@@ -198,9 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         else if (more) { LOAD_R(RN, (st_) + 2 - NST, rec0 + KG) }                                       \
         if ((st_) == SPT && more) { LOAD_PATCH(c0 + CK) }                                               \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        const int tapoff = (((st_) / SPT) / 3) * ROWP + (((st_) / SPT) % 3) * PSTR;                     \
-        MMA_KG(((st_) % SPT) * KPS, RC##_00, RC##_10)                                                   \
-        if (KPS > 1) MMA_KG(((st_) % SPT) * KPS + 1, RC##_01, RC##_11)                                  \
+        KGSTEP((st_) * KPS, RC##_00, RC##_10)                                                           \
+        if constexpr (KPS > 1) KGSTEP((st_) * KPS + 1, RC##_01, RC##_11)                                \
         if (PBUF == 2 && (st_) == 6 * SPT && more) { STORE_PATCH(c0 + CK, (chunk + 1) & 1) }            \
     }
 #define STEP3(s_) STEP((s_), r0, r2) STEP((s_) + 1, r1, r0) STEP((s_) + 2, r2, r1)
@@ -217,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         const unsigned char* pcur = smem + (PBUF == 2 ? (chunk & 1) : 0) * CF::PATCH_BYTES;
         const bool more = c0 + CK < Cin;
         const int rec0 = chunk * KG;                     // record offset of this chunk inside a (cout block, tap) row
+        A_LOAD(ae, 0)
         STEP3(0) STEP3(3) STEP3(6)
         if constexpr (SPT == 2) { STEP3(9) STEP3(12) STEP3(15) }
         if (PBUF == 1 && more) {                         // single patch buffer: everyone done reading, then refill
@@ -229,7 +255,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #undef LOAD_R
 #undef STEP
 #undef STEP3
-#undef MMA_KG
+#undef KGSTEP
+#undef A_MMA
+#undef A_LOAD
+#undef LDSA
+#undef A_OFF
 #undef LOAD_PATCH
 #undef STORE_PATCH
 
@@ -314,19 +344,30 @@ static ConvPlan conv_plan(int N, int H, int W, int Cout, int imgs_per_group) {
 #ifndef NO_T16
     else if (narrow && H >= 12 && W >= 12) { g.TI = 1; g.TH = 16; g.TW = 16; }
 #endif
+#ifdef WIDE_T16
+    else if (!narrow && H >= 16 && W >= 16 &&
+             (long)N * ((H + 15) / 16) * ((W + 15) / 16) * (Cout / 128) >= WIDE_T16) { g.TI = 1; g.TH = 16; g.TW = 16; }
+#endif
     else { g.TI = 1; g.TH = 8; g.TW = 16; }
     g.tiles_y = (H + g.TH - 1) / g.TH;
     g.tiles_x = (W + g.TW - 1) / g.TW;
     g.n_mtiles = ((N + g.TI - 1) / g.TI) * g.tiles_y * g.tiles_x;
     p.BN = (!narrow && (long)g.n_mtiles * (Cout / 128) >= 512) ? 128 : 64;
-    if (g.TH == 16) p.BN = 64;
+    if (g.TH == 16) p.BN = narrow ? 64 : 128;
     return p;
 }
 
 template <typename T, int CKB>
 static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
+#ifdef WIDE_T16
+    if (g.TH == 16 && p.BN == 128) return launch_conv<T, CKB, 16, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
+#endif
+#ifdef NARROW_22
+    if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
+#else
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
+#endif
     if (g.TI == 1) {
         if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
         return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);

@@ -191,6 +191,230 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad2: the bf16 / 8x16-tile / full 64-channel case (16 of the 18 layers of BiDateNet) as a software pipeline.
+// Same block tile (64 co x 64 ci x 9 taps, 4 waves, one block per CU), but
+//  * LDS is double buffered (2 x (patch 10x18 px + dz 128 px) x 192 B = 116 KB): ONE barrier per chunk, and the
+//    next chunk is staged while the current one is in the MFMAs;
+//  * global loads run TWO chunks ahead through two register sets (HBM latency is longer than one chunk of one
+//    wave per SIMD);
+//  * the MFMAs walk the patch ROW by ROW: the three fragments of patch row pr feed tile rows pr, pr-1, pr-2
+//    (taps r = 0, 1, 2), so every patch fragment is read from LDS once (30 fragment reads per chunk instead of
+//    72), and the reads of row pr+1 are issued ahead of the MFMAs of row pr;
+//  * every LDS read is one base register + an immediate offset, staging is branch free (masks, clamped
+//    addresses) and is spread over the rows so its VALU work sits in the shadow of the MFMAs.
+struct Wg2 {
+    static constexpr int PW = 18, PH = 10, STR = 192;
+    static constexpr int PATCH_BYTES = 6 * 32 * STR;             // 180 patch pixels, padded to the 192 unit slots the staging threads own
+    static constexpr int DZ_BYTES = 128 * STR;
+    static constexpr int BUF = PATCH_BYTES + DZ_BYTES;
+    static constexpr int SMEM = 2 * BUF;
+};
+
+template <bool USE_BN>
+__global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
+    constexpr int PW = Wg2::PW, STR = Wg2::STR, BUF = Wg2::BUF, PATCH_BYTES = Wg2::PATCH_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.n_cot * a.n_cit;
+    const int tile = logical % ntile, split = logical / ntile;
+    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
+    const int Cin = a.C0 + a.C1;
+
+    const bf16s* src; int Csrc, cs;
+    if (ci0 < a.C0) { src = reinterpret_cast<const bf16s*>(a.in0); Csrc = a.C0; cs = ci0; }
+    else { src = reinterpret_cast<const bf16s*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
+    const bf16s* dzp = reinterpret_cast<const bf16s*>(a.dz);
+
+    // ---- staging ownership: thread = (pixel lane u_pix, 16-byte channel unit sub); units i = u_pix + 32 i
+    const int u_pix = tid >> 3, sub = tid & 7, sub_e = sub * 8;
+    const unsigned wbase = u_pix * STR + sub * 16;             // LDS offset of unit 0; unit i adds i*32*STR
+    int prel[6], pyx[6];                                       // patch units: pixel offset from the tile origin, (y-1, x-1)
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
+        prel[i] = (yy - 1) * a.W + (xx - 1);
+        pyx[i] = pix < Wg2::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
+    }
+    const int dpx = u_pix & 15, dpy0 = u_pix >> 4;             // dz units: tile pixel (dpy0 + 2 i, dpx)
+    const int drel0 = dpy0 * a.W + dpx;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    uint4 pA[6], dA[4], pB[6], dB[4];                          // the two prefetch register sets
+    unsigned mA = 0, mB = 0;                                   // validity bits: patch unit i -> bit i, dz unit i -> bit 8+i
+    int gA = 0, gB = 0;                                        // BatchNorm statistic group of each set's image
+    int cur_grp = -1;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
+
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+
+    // issue the global loads of chunk q_ into set (P, D, M, G); out-of-image units load a clamped address and
+    // are zeroed by their mask bit when they are written to LDS
+#define WG_LOAD(P, D, M, G, q_)                                                                          \
+    {                                                                                                   \
+        const int qq_ = (q_);                                                                           \
+        const bool live_ = qq_ < q_end;                                                                 \
+        const int qc_ = live_ ? qq_ : q_begin;                                                          \
+        const int tx_ = qc_ % a.tiles_x, ty_ = (qc_ / a.tiles_x) % a.tiles_y, n0_ = qc_ / (a.tiles_x * a.tiles_y); \
+        const int y0_ = ty_ * 8, x0_ = tx_ * 16;                                                        \
+        const int pixbase_ = (n0_ * a.H + y0_) * a.W + x0_;                                             \
+        G = n0_ / a.imgs_per_group;                                                                     \
+        unsigned m_ = 0;                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) {                                                  \
+            const int y_ = y0_ + (pyx[i] >> 16), x_ = x0_ + (short)(pyx[i] & 0xffff);                   \
+            const bool ok_ = live_ && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;     \
+            const int off_ = ok_ ? (pixbase_ + prel[i]) * Csrc + cs + sub_e : 0;                        \
+            P[i] = *reinterpret_cast<const uint4*>(src + off_);                                         \
+            m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
+            const bool ok_ = live_ && (y0_ + dpy0 + 2 * i) < a.H && (x0_ + dpx) < a.W;                  \
+            const int off_ = ok_ ? (pixbase_ + drel0 + 2 * i * a.W) * a.Cout + co0 + sub_e : 0;         \
+            D[i] = *reinterpret_cast<const uint4*>(dzp + off_);                                         \
+            m_ |= (ok_ ? 1u : 0u) << (8 + i);                                                           \
+        }                                                                                               \
+        M = m_;                                                                                         \
+    }
+    // BatchNorm scale / shift rows of statistic group g_ for this thread's 8 channels (uniform branch, rare)
+#define WG_GROUP(g_)                                                                                     \
+    if (USE_BN && (g_) != cur_grp) {                                                                    \
+        cur_grp = (g_);                                                                                 \
+        const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub_e;                              \
+        const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub_e;                              \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }                \
+    }
+    // write one unit of a register set into LDS buffer `wb_` (byte address of the buffer)
+#define WG_ST_P(P, M, i_, wb_)                                                                           \
+    {                                                                                                   \
+        uint4 v_ = P[i_];                                                                               \
+        if (USE_BN) v_ = bnrelu_unit<bf16s>(v_, sc, sh);                                                \
+        const bool ok_ = ((M) >> (i_)) & 1u;                                                            \
+        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+        *reinterpret_cast<uint4*>((wb_) + wbase + (i_) * 32 * STR) = v_;                                \
+    }
+#define WG_ST_D(D, M, i_, wb_)                                                                           \
+    {                                                                                                   \
+        uint4 v_ = D[i_];                                                                               \
+        const bool ok_ = ((M) >> (8 + (i_))) & 1u;                                                      \
+        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+        *reinterpret_cast<uint4*>((wb_) + PATCH_BYTES + wbase + (i_) * 32 * STR) = v_;                  \
+    }
+
+    // ---- MFMA operand addressing: lane's transposing-read role = pixel kpix of a 4-pixel group, 4-channel piece
+    // (lane&3) of 16-channel block ((lane>>4)&1) of the wave's 32 channels
+    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int kpix = (lane & 15) >> 2;
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + wm * 64 + chan_b;     // + ks*16*STR (+4*STR)
+    const unsigned b_base = (half * 8 + kpix) * STR + wn * 64 + chan_b;                   // + (pr*PW + c)*STR (+4*STR)
+    uint4 af[4], bq[2][3];
+#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
+#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + b_base + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + b_base + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
+    // patch row pr_: prefetch the fragments of row pr_+1 (and dz row pr_+1), then the MFMAs of every (tile row, r)
+    // pair that reads patch row pr_, then this row's share of the staging (STG_)
+#define WG_ROW(pr_, STG_)                                                                                \
+    {                                                                                                   \
+        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
+        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) }                     \
+        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
+        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) }       \
+        STG_                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+    // one chunk: compute from buffer rb_, stage set (P, D, M, G) (chunk q+1) into buffer wb_, then refill that set
+    // with chunk q+3
+#define WG_CHUNK(rb_, wb_, P, D, M, G, qn_)                                                              \
+    {                                                                                                   \
+        const unsigned char* rb = (rb_);                                                                \
+        unsigned char* wb = (wb_);                                                                      \
+        WG_GROUP(G)                                                                                     \
+        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)                        \
+        WG_ROW(0, )                                                                                     \
+        WG_ROW(1, )                                                                                     \
+        WG_ROW(2, WG_ST_P(P, M, 0, wb) WG_ST_P(P, M, 1, wb))                                            \
+        WG_ROW(3, WG_ST_P(P, M, 2, wb) WG_ST_P(P, M, 3, wb))                                            \
+        WG_ROW(4, WG_ST_P(P, M, 4, wb) WG_ST_P(P, M, 5, wb))                                            \
+        WG_ROW(5, WG_ST_D(D, M, 0, wb) WG_ST_D(D, M, 1, wb))                                            \
+        WG_ROW(6, WG_ST_D(D, M, 2, wb) WG_ST_D(D, M, 3, wb))                                            \
+        WG_ROW(7, WG_LOAD(P, D, M, G, qn_))                                                             \
+        WG_ROW(8, )                                                                                     \
+        WG_ROW(9, )                                                                                     \
+    }
+
+    unsigned char* buf0 = smem;
+    unsigned char* buf1 = smem + BUF;
+    if (q_begin < q_end) {
+        WG_LOAD(pA, dA, mA, gA, q_begin)
+        WG_LOAD(pB, dB, mB, gB, q_begin + 1)
+        WG_GROUP(gA)
+#pragma unroll
+        for (int i = 0; i < 6; i++) WG_ST_P(pA, mA, i, buf0)
+#pragma unroll
+        for (int i = 0; i < 4; i++) WG_ST_D(dA, mA, i, buf0)
+        WG_LOAD(pA, dA, mA, gA, q_begin + 2)
+        __syncthreads();
+        for (int q = q_begin; q < q_end; q += 2) {
+            WG_CHUNK(buf0, buf1, pB, dB, mB, gB, q + 3)
+            __syncthreads();
+            WG_CHUNK(buf1, buf0, pA, dA, mA, gA, q + 4)   // an odd tail runs on an all-zero chunk (masks are clear past q_end)
+            __syncthreads();
+        }
+    }
+#undef WG_LOAD
+#undef WG_GROUP
+#undef WG_ST_P
+#undef WG_ST_D
+#undef TRP
+#undef LDA
+#undef LDB
+#undef WG_MMA
+#undef WG_ROW
+#undef WG_CHUNK
+
+    // partial[split][tap][co][ci]
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                a.partial[(((size_t)split * 9 + tap) * a.Cout + co) * Cin + ci] = acc[tap][r];
+            }
+    }
+}
+
+template <bool USE_BN>
+static int launch_wgrad2(const WgradArgs& a, hipStream_t st) {
+    auto kern = wgrad2_kernel<USE_BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2::SMEM);
+        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad2: hipFuncSetAttribute(%d): %s", Wg2::SMEM, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), Wg2::SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad2");
+    return BDN_OK;
+}
+
 // dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
 // Block = SL split lanes x (256/SL) (co,ci) pairs: reads are coalesced along ci, the SL lanes walk the
 // splits in parallel (fixed order -> deterministic), an LDS tree combines them, and each pair's nine taps
@@ -306,7 +530,16 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (dtype == BDN_BF16) {
-        if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
+        // the pipelined kernel covers full 64-channel input tiles on 8x16 spatial tiles whose tensors stay below 2^31 elements
+        const bool v2 = !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 &&
+                        (size_t)N * H * W * (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1)) < ((size_t)1 << 31);
+#ifdef WG_NO_V2
+        const bool use_v2 = false;
+#else
+        const bool use_v2 = v2;
+#endif
+        if (use_v2) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
+        else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);
     } else if (dtype == BDN_F32) {
         if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1, true>(a, st) : launch_wgrad<float, 8, 8, 2, true>(a, st);

@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage: tools/pmc_mem.sh <tag> <one_conv args...>  -- memory-path + issue counters of one conv/wgrad shape (separate --pmc passes)
+tag=$1; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/pmcm_$tag
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
+           "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR"; do
+  rocprofv3 --pmc $set -d $out/p$i -o pmc --output-format csv -- python tools/one_conv.py "$@" > $out.log$i 2>&1
+  i=$((i+1))
+done
+python - <<PY
+import csv, glob, collections
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(lambda: collections.Counter())
+for f in glob.glob('$out/p*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name'].split('(')[0][:80]
+        agg[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
+for k,v in agg.items():
+    if 'conv3x3_kernel' in k or 'wgrad_kernel' in k:
+        print(k)
+        for c,val in sorted(v.items()): print(f'   {c:36s} {val/n[k][c]:.5g}')
+PY
