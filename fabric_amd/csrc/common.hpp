@@ -82,6 +82,24 @@ __device__ __forceinline__ uint4 bnrelu_unit(const uint4& u, const float* sc, co
     for (int i = 0; i < N; i++) f[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
     return Unit<T>::pack(f);
 }
+// bf16: two channels per dword through the packed pipes -- v_pk_fma_f32, v_cvt_pk_bf16_f32, and the ReLU as a
+// signed 16-bit max with 0 on the rounded pair (a negative bf16 is a negative int16; rounding keeps the sign, so
+// round(max(x,0)) == max(round(x),0)).  6 VALU per dword instead of 9.
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+__device__ __forceinline__ uint32_t bnrelu_pair(uint32_t u, float s0, float s1, float t0, float t1) {
+    const f32x2_t z = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+    const f32x2_t s = {s0, s1}, t = {t0, t1};
+    const f32x2_t y = __builtin_elementwise_fma(z, s, t);
+    const bf16x2_t r = __builtin_convertvector(y, bf16x2_t);
+    const s16x2_t zero = {0, 0};
+    const s16x2_t q = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, r), zero);
+    return __builtin_bit_cast(uint32_t, q);
+}
+template <>
+__device__ __forceinline__ uint4 bnrelu_unit<bf16s>(const uint4& u, const float* sc, const float* sh) {
+    return make_uint4(bnrelu_pair(u.x, sc[0], sc[1], sh[0], sh[1]), bnrelu_pair(u.y, sc[2], sc[3], sh[2], sh[3]),
+                      bnrelu_pair(u.z, sc[4], sc[5], sh[4], sh[5]), bnrelu_pair(u.w, sc[6], sc[7], sh[6], sh[7]));
+}
 
 // Filter image in MFMA fragment order (what conv3x3_kernel streams from L2): one contiguous 1 KB record per
 // (32 output channels, tap, k-group of 32 bytes of input channels); inside a record lane l owns 16 bytes:

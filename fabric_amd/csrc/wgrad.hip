@@ -235,15 +235,24 @@ __global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
     // ---- staging ownership: thread = (pixel lane u_pix, 16-byte channel unit sub); units i = u_pix + 32 i
     const int u_pix = tid >> 3, sub = tid & 7, sub_e = sub * 8;
     const unsigned wbase = u_pix * STR + sub * 16;             // LDS offset of unit 0; unit i adds i*32*STR
-    int prel[6], pyx[6];                                       // patch units: pixel offset from the tile origin, (y-1, x-1)
+    int pyx[6];                                                // patch units: (y-1, x-1) relative to the tile origin
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
-        prel[i] = (yy - 1) * a.W + (xx - 1);
         pyx[i] = pix < Wg2::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
     }
     const int dpx = u_pix & 15, dpy0 = u_pix >> 4;             // dz units: tile pixel (dpy0 + 2 i, dpx)
-    const int drel0 = dpy0 * a.W + dpx;
+    // byte offsets from the chunk's uniform base pointers (32-bit: the dispatcher keeps tensors below 2^31 elements)
+    unsigned poff[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
+        poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub_e) * 2);
+    }
+    const unsigned poff_c = (unsigned)((((a.W + 1)) * Csrc + cs + sub_e) * 2);        // the tile's origin pixel: always inside
+    const unsigned drow = (unsigned)(a.W * a.Cout * 2);
+    const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + sub_e) * 2);
+    const unsigned doff_c = (unsigned)((co0 + sub_e) * 2);
 
     f32x16 acc[9];
 #pragma unroll
@@ -261,33 +270,41 @@ __global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
 
     const int q_begin = split * a.per_split;
     const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    int lq = q_begin;                                          // load cursor: chunk index and its tile coordinates
+    int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
+    int lg = ln / a.imgs_per_group;
+    int lpix = 0;
 
-    // issue the global loads of chunk q_ into set (P, D, M, G); out-of-image units load a clamped address and
-    // are zeroed by their mask bit when they are written to LDS
-#define WG_LOAD(P, D, M, G, q_)                                                                          \
+    // issue the global loads of the NEXT chunk in sequence (chunks are always requested in order q_begin, +1, ...)
+    // into set (P, D, M, G).  Addresses are one uniform base (the tile's top-left halo pixel) plus a per-thread
+    // constant byte offset; out-of-image units load the tile's origin pixel instead and are zeroed by their mask
+    // bit when they are written to LDS.  The tile coordinates advance incrementally (no division per chunk).
+#define WG_LOAD(P, D, M, G)                                                                              \
     {                                                                                                   \
-        const int qq_ = (q_);                                                                           \
-        const bool live_ = qq_ < q_end;                                                                 \
-        const int qc_ = live_ ? qq_ : q_begin;                                                          \
-        const int tx_ = qc_ % a.tiles_x, ty_ = (qc_ / a.tiles_x) % a.tiles_y, n0_ = qc_ / (a.tiles_x * a.tiles_y); \
-        const int y0_ = ty_ * 8, x0_ = tx_ * 16;                                                        \
-        const int pixbase_ = (n0_ * a.H + y0_) * a.W + x0_;                                             \
-        G = n0_ / a.imgs_per_group;                                                                     \
+        const bool live_ = lq < q_end;                                                                  \
+        const int y0_ = lty * 8, x0_ = ltx * 16;                                                        \
+        const int pixbase_ = live_ ? (ln * a.H + y0_) * a.W + x0_ : lpix;   /* past the end: any valid tile, all units masked */ \
+        lpix = pixbase_;                                                                                \
+        const unsigned char* sp_ = reinterpret_cast<const unsigned char*>(src) + ((long)(pixbase_ - a.W - 1) * Csrc) * 2; \
+        const unsigned char* dp_ = reinterpret_cast<const unsigned char*>(dzp) + ((long)pixbase_ * a.Cout) * 2; \
+        if (live_) G = lg;                                                                              \
         unsigned m_ = 0;                                                                                \
         _Pragma("unroll") for (int i = 0; i < 6; i++) {                                                  \
             const int y_ = y0_ + (pyx[i] >> 16), x_ = x0_ + (short)(pyx[i] & 0xffff);                   \
             const bool ok_ = live_ && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;     \
-            const int off_ = ok_ ? (pixbase_ + prel[i]) * Csrc + cs + sub_e : 0;                        \
-            P[i] = *reinterpret_cast<const uint4*>(src + off_);                                         \
+            P[i] = *reinterpret_cast<const uint4*>(sp_ + (ok_ ? poff[i] : poff_c));                     \
             m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
             const bool ok_ = live_ && (y0_ + dpy0 + 2 * i) < a.H && (x0_ + dpx) < a.W;                  \
-            const int off_ = ok_ ? (pixbase_ + drel0 + 2 * i * a.W) * a.Cout + co0 + sub_e : 0;         \
-            D[i] = *reinterpret_cast<const uint4*>(dzp + off_);                                         \
+            D[i] = *reinterpret_cast<const uint4*>(dp_ + (ok_ ? doff0 + (unsigned)(2 * i) * drow : doff_c)); \
             m_ |= (ok_ ? 1u : 0u) << (8 + i);                                                           \
         }                                                                                               \
         M = m_;                                                                                         \
+        if (live_) {                                                                                    \
+            lq++;                                                                                       \
+            if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
+        }                                                                                               \
     }
     // BatchNorm scale / shift rows of statistic group g_ for this thread's 8 channels (uniform branch, rare)
 #define WG_GROUP(g_)                                                                                     \
@@ -339,8 +356,8 @@ __global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
         __builtin_amdgcn_sched_barrier(0);                                                              \
     }
     // one chunk: compute from buffer rb_, stage set (P, D, M, G) (chunk q+1) into buffer wb_, then refill that set
-    // with chunk q+3
-#define WG_CHUNK(rb_, wb_, P, D, M, G, qn_)                                                              \
+    // with the next chunk in sequence (q+3)
+#define WG_CHUNK(rb_, wb_, P, D, M, G)                                                              \
     {                                                                                                   \
         const unsigned char* rb = (rb_);                                                                \
         unsigned char* wb = (wb_);                                                                      \
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
         WG_ROW(4, WG_ST_P(P, M, 4, wb) WG_ST_P(P, M, 5, wb))                                            \
         WG_ROW(5, WG_ST_D(D, M, 0, wb) WG_ST_D(D, M, 1, wb))                                            \
         WG_ROW(6, WG_ST_D(D, M, 2, wb) WG_ST_D(D, M, 3, wb))                                            \
-        WG_ROW(7, WG_LOAD(P, D, M, G, qn_))                                                             \
+        WG_ROW(7, WG_LOAD(P, D, M, G))                                                             \
         WG_ROW(8, )                                                                                     \
         WG_ROW(9, )                                                                                     \
     }
@@ -361,19 +378,19 @@ __global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
     unsigned char* buf0 = smem;
     unsigned char* buf1 = smem + BUF;
     if (q_begin < q_end) {
-        WG_LOAD(pA, dA, mA, gA, q_begin)
-        WG_LOAD(pB, dB, mB, gB, q_begin + 1)
+        WG_LOAD(pA, dA, mA, gA)
+        WG_LOAD(pB, dB, mB, gB)
         WG_GROUP(gA)
 #pragma unroll
         for (int i = 0; i < 6; i++) WG_ST_P(pA, mA, i, buf0)
 #pragma unroll
         for (int i = 0; i < 4; i++) WG_ST_D(dA, mA, i, buf0)
-        WG_LOAD(pA, dA, mA, gA, q_begin + 2)
+        WG_LOAD(pA, dA, mA, gA)
         __syncthreads();
         for (int q = q_begin; q < q_end; q += 2) {
-            WG_CHUNK(buf0, buf1, pB, dB, mB, gB, q + 3)
+            WG_CHUNK(buf0, buf1, pB, dB, mB, gB)
             __syncthreads();
-            WG_CHUNK(buf1, buf0, pA, dA, mA, gA, q + 4)   // an odd tail runs on an all-zero chunk (masks are clear past q_end)
+            WG_CHUNK(buf1, buf0, pA, dA, mA, gA)   // an odd tail runs on an all-zero chunk (masks are clear past q_end)
             __syncthreads();
         }
     }

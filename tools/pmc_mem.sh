@@ -20,7 +20,7 @@ for f in glob.glob('$out/p*/*counter_collection.csv'):
         k=r['Kernel_Name'].split('(')[0][:80]
         agg[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
 for k,v in agg.items():
-    if 'conv3x3_kernel' in k or 'wgrad_kernel' in k:
+    if 'conv3x3_kernel' in k or ('wgrad' in k and 'reduce' not in k):
         print(k)
         for c,val in sorted(v.items()): print(f'   {c:36s} {val/n[k][c]:.5g}')
 PY
