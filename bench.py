@@ -84,8 +84,8 @@ def pmc_traffic(kernel, precision):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=64, help='patch pairs per GPU')
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--channels', type=int, default=13)
@@ -120,15 +120,28 @@ def main():
     lbl = (torch.rand(B, S, S, generator=g) < 0.1).to(torch.uint8)
     x1, x2, lbl = x1.to(dev), x2.to(dev), lbl.to(dev)     # resident in HBM before the timed region
 
+    eng = model.engine()
     for _ in range(args.warmup):
         ts.step(x1, x2, lbl)
-    eng = model.engine()
+    # Which conv3x3 instantiation dominates?  One fully instrumented, UNTIMED step decides (every event pair is a
+    # ~150 us pipeline bubble on this stack, so the timed region only brackets the launches of that one kernel,
+    # and only during its first EVENT_STEPS steps).
+    conv_all = None
+    if not args.no_roofline:
+        torch.cuda.synchronize()
+        eng.prof, eng.prof_filter = [], None
+        ts.step(x1, x2, lbl)
+        torch.cuda.synchronize()
+        raw, eng.prof = eng.prof, None
+        conv_all = {}
+        for name, flops, e0, e1 in raw:
+            a = conv_all.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
+        eng.prof_filter = max(conv_all.items(), key=lambda kv: kv[1][2])[0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events bracket every conv3x3 launch during the first EVENT_STEPS steps of the timed region only:
-    # a timing event is a pipeline bubble on this stack (~15 us each), so they are kept to a few steps
-    EVENT_STEPS = min(3, args.steps)
+    EVENT_STEPS = min(2, args.steps)
     if not args.no_roofline:
         eng.prof = []
     prof = None
@@ -160,13 +173,14 @@ def main():
         name, (cnt, flops, secs) = max(agg.items(), key=lambda kv: kv[1][2])
         peak = MFMA_BF16_PEAK if args.precision == 'bf16' else MFMA_F32_PEAK
         achieved = flops / secs
-        conv_total = sum(v[2] for v in agg.values())
+        conv_total = sum(v[2] for v in conv_all.values())
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved / 1e12, 'peak': peak / 1e12,
                     'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_traffic(name, args.precision),
                     'launches_per_step': cnt / EVENT_STEPS, 'event_steps': EVENT_STEPS, 'avg_launch_us': secs / cnt * 1e6,
                     'flop_per_launch': flops / cnt,
-                    'all_conv3x3_launches': {'time_frac_of_step': (conv_total / EVENT_STEPS) / (elapsed / args.steps),
-                                             'achieved': sum(v[1] for v in agg.values()) / conv_total / 1e12}}
+                    'all_conv3x3_launches': {'source': 'one fully instrumented untimed step',
+                                             'seconds_per_step': conv_total,
+                                             'achieved': sum(v[1] for v in conv_all.values()) / conv_total / 1e12}}
     if rank == 0:
         pairs = args.steps * B * world
         value = pairs / elapsed

@@ -217,8 +217,11 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dA, int ldA, const T*
 
 // per-block partials [G*bpg][2][C] (bpg <= 1024 rows per group) -> sums[g][2][C]; dgamma / dbeta are summed over
 // groups.  1024 threads = 64 row lanes x 16 channels, double accumulation, fixed order.
+// raw_bn != nullptr: the second partial is the raw moment sum g*z (fused producers: the conv data-gradient epilogue,
+// enc_skip_bwd, outc_bwd), converted here in double:  sum g*xhat = invstd * (sum g*z - mean * sum g).
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks_per_group, int G, int C,
-                                       float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                       float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       const float* __restrict__ raw_bn) {
     __shared__ double sm[64][16][2];
     const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
     const int c = blockIdx.x * 16 + cl;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
         }
         if (rl == 0 && c < C) {
             a0 = sm[0][cl][0]; a1 = sm[0][cl][1];
+            if (raw_bn) a1 = (double)bn_row(raw_bn, g, 1, C)[c] * (a1 - (double)bn_row(raw_bn, g, 0, C)[c] * a0);
             sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
             sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
             t0 += a0; t1 += a1;
@@ -312,12 +316,43 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(G * bpg), dim3(256), 256 * EPU * 2 * sizeof(float), st,
                        (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, ppb, C, ws);
     BDN_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, ws, bpg, G, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, ws, bpg, G, C, sums, dgamma, dbeta, (const float*)nullptr);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
                        (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
     BDN_CHECK_LAUNCH("bn_bwd_apply");
     return BDN_OK;
+}
+
+template <typename T>
+static int bn_bwd_apply_impl(const void* dA, int ldA, const void* z, const float* bn, int imgs_per_group,
+                             int N, int H, int W, int C, const float* partial, int rows_per_group, int raw_moment,
+                             float* sums, float* dgamma, float* dbeta, void* dz, hipStream_t st) {
+    constexpr int EPU = ET<T>::EPU;
+    const int G = N / imgs_per_group;
+    const int ppg = imgs_per_group * H * W;
+    const int ppb = bnb_pix_per_block(ppg, 256 / (C / EPU));
+    const int bpg = (ppg + ppb - 1) / ppb;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partial, rows_per_group, G, C, sums, dgamma, dbeta,
+                       raw_moment ? bn : (const float*)nullptr);
+    BDN_CHECK_LAUNCH("bn_bwd_finalize");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
+                       (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
+    BDN_CHECK_LAUNCH("bn_bwd_apply");
+    return BDN_OK;
+}
+
+extern "C" int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const float* bn,
+                                int imgs_per_group, int N, int H, int W, int C,
+                                const float* partial, int rows_per_group, int raw_moment,
+                                float* sums, float* dgamma, float* dbeta, void* dz, void* stream) {
+    if (!dA || !z || !bn || !partial || !sums || !dz) BDN_FAIL(BDN_E_ARG, "bn_bwd_apply: null pointer");
+    if (N <= 0 || imgs_per_group <= 0 || N % imgs_per_group || C % 16 || ldA < C || ldA % 16 || rows_per_group <= 0)
+        BDN_FAIL(BDN_E_SHAPE, "bn_bwd_apply: bad shape");
+    if (C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "bn_bwd_apply: C=%d must divide 1024", C);
+    if (dtype == BDN_BF16) return bn_bwd_apply_impl<bf16s>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, (hipStream_t)stream);
+    if (dtype == BDN_F32) return bn_bwd_apply_impl<float>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, (hipStream_t)stream);
+    BDN_FAIL(BDN_E_ARG, "bn_bwd_apply: bad dtype");
 }
 
 extern "C" int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* bn,

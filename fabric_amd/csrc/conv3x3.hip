@@ -30,6 +30,10 @@ struct ConvArgs {
     float* stats_partial;        // [n_mtiles][2][Cout] or null
     int N, H, W, Cout;
     int tiles_y, tiles_x, n_ntiles;
+    // data-gradient launches only: the output is dA of the layer whose raw output is bs_z and whose BatchNorm table
+    // is bs_bn; the epilogue then also emits that layer's BatchNorm-backward partial sums (stats_partial, same
+    // [n_mtiles][2][Cout] layout):  sum_p g  and  sum_p g*z  with  g = dA * [scale*z + shift > 0]
+    const void* bs_z; const float* bs_bn;
 };
 
 template <typename T> struct Mma;
@@ -70,7 +74,7 @@ struct ConvCfg {
     static constexpr int OSTR = BN * ES + 16;
     static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
     static constexpr int MAIN_BYTES = PBUF * PATCH_BYTES;
-    static constexpr int EPI_BYTES = BM * OSTR + WM * BN * 2 * 4;
+    static constexpr int EPI_BYTES = BM * OSTR + 4 * BN * 2 * 4;
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     // ------------------------------------------------------------------ epilogue (LDS reused)
     unsigned char* otile = smem;
     float* red = reinterpret_cast<float*>(smem + CF::BM * CF::OSTR);
-    const bool do_stats = a.stats_partial != nullptr;
+    const bool do_stats = a.stats_partial != nullptr && a.bs_z == nullptr;
     const bool full_tile = (n0 + TI <= a.N) && (y0 + TH <= a.H) && (x0 + TW <= a.W);   // block-uniform
 #pragma unroll
     for (int nj = 0; nj < NJ; nj++) {
@@ -302,14 +306,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         a.stats_partial[((size_t)mtile * 2 + 1) * a.Cout + col0 + tid] = q;
     }
     constexpr int UPR = BN * CF::ES / 16;                    // 16-byte units per output pixel row
+    static_assert(256 % UPR == 0 && UPR <= 64, "a thread keeps one channel unit through the copy-out loop");
     T* outp = reinterpret_cast<T*>(a.out);
+    const bool bs = a.bs_z != nullptr;                       // block-uniform
+    const T* bsz = reinterpret_cast<const T*>(a.bs_z);
+    const int bsub = (tid % UPR) * EPU;                      // this thread's channels inside the block's column tile
+    float bs0[EPU], bs1[EPU], bsc[EPU], bsh[EPU];
+#pragma unroll
+    for (int i = 0; i < EPU; i++) { bs0[i] = 0.f; bs1[i] = 0.f; bsc[i] = 0.f; bsh[i] = 0.f; }
+    if (bs) {
+        const float* ps = bn_row(a.bs_bn, grp, 2, a.Cout) + col0 + bsub;
+        const float* ph = bn_row(a.bs_bn, grp, 3, a.Cout) + col0 + bsub;
+#pragma unroll
+        for (int i = 0; i < EPU; i++) { bsc[i] = ps[i]; bsh[i] = ph[i]; }
+    }
     for (int u = tid; u < CF::BM * UPR; u += 256) {
         const int slot = u / UPR, sub = u % UPR;
         int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
         const int n = n0 + ti, y = y0 + py, x = x0 + px;
         if (n < a.N && y < a.H && x < a.W) {
             uint4 v = *reinterpret_cast<const uint4*>(otile + slot * CF::OSTR + sub * 16);
-            *reinterpret_cast<uint4*>(outp + ((size_t)(n * a.H + y) * a.W + x) * a.Cout + col0 + sub * EPU) = v;
+            const size_t o = ((size_t)(n * a.H + y) * a.W + x) * a.Cout + col0 + sub * EPU;
+            *reinterpret_cast<uint4*>(outp + o) = v;
+            if (bs) {                                        // the stored (rounded) gradient is what BatchNorm backward sees
+                float fg[EPU], fz[EPU];
+                Unit<T>::unpack(v, fg);
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(bsz + o), fz);
+#pragma unroll
+                for (int i = 0; i < EPU; i++) {
+                    const float g = fmaf(fz[i], bsc[i], bsh[i]) > 0.f ? fg[i] : 0.f;
+                    bs0[i] += g; bs1[i] = fmaf(g, fz[i], bs1[i]);
+                }
+            }
+        }
+    }
+    if (bs) {
+        // lanes tid, tid+UPR, ... of a wave hold the same channels: butterfly over those lane bits, then the four
+        // waves meet in LDS (fixed order -> deterministic)
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+#pragma unroll
+            for (int m = UPR; m < 64; m <<= 1) { bs0[i] += __shfl_xor(bs0[i], m); bs1[i] += __shfl_xor(bs1[i], m); }
+        }
+        if (lane < UPR) {
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                red[((wave * BN) + lane * EPU + i) * 2] = bs0[i];
+                red[((wave * BN) + lane * EPU + i) * 2 + 1] = bs1[i];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; wv++) { t0 += red[(wv * BN + tid) * 2]; t1 += red[(wv * BN + tid) * 2 + 1]; }
+            a.stats_partial[((size_t)mtile * 2 + 0) * a.Cout + col0 + tid] = t0;
+            a.stats_partial[((size_t)mtile * 2 + 1) * a.Cout + col0 + tid] = t1;
         }
     }
 }
@@ -381,10 +433,11 @@ extern "C" int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_pe
     return conv_plan(N, H, W, Cout, imgs_per_group).g.n_mtiles;
 }
 
-extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
-                           int in_mode, const float* in_bn, int imgs_per_group,
-                           const void* w, const float* bias, void* out, float* stats_partial,
-                           int N, int H, int W, int Cout, void* stream) {
+static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int C1,
+                        int in_mode, const float* in_bn, int imgs_per_group,
+                        const void* w, const float* bias, void* out, float* stats_partial,
+                        const void* bs_z, const float* bs_bn,
+                        int N, int H, int W, int Cout, void* stream) {
     if (!in0 || !w || !out) BDN_FAIL(BDN_E_ARG, "conv3x3: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
         BDN_FAIL(BDN_E_SHAPE, "conv3x3: bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
@@ -398,11 +451,11 @@ extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, 
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
+    a.bs_z = bs_z; a.bs_bn = bs_bn;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int Cin = C0 + C1;
     if (dtype == BDN_BF16) {
         // channel chunk: 64 channels (128 B) when both sources allow it, else 16 channels (32 B)
         if (C0 % 64 == 0 && C1 % 64 == 0) return dispatch_conv<bf16s, 128>(a, g, st);
@@ -413,6 +466,21 @@ extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, 
         if (C0 % 16 == 0 && C1 % 16 == 0) return dispatch_conv<float, 64>(a, g, st);
         BDN_FAIL(BDN_E_SHAPE, "conv3x3(f32): C0=%d C1=%d must be multiples of 16", C0, C1);
     }
-    (void)Cin;
     BDN_FAIL(BDN_E_ARG, "conv3x3: bad dtype %d", dtype);
+}
+
+extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
+                           int in_mode, const float* in_bn, int imgs_per_group,
+                           const void* w, const float* bias, void* out, float* stats_partial,
+                           int N, int H, int W, int Cout, void* stream) {
+    return conv3x3_impl(dtype, in0, C0, in1, C1, in_mode, in_bn, imgs_per_group, w, bias, out, stats_partial,
+                        nullptr, nullptr, N, H, W, Cout, stream);
+}
+
+extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad, void* dA,
+                                    const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
+                                    int N, int H, int W, int Cout, void* stream) {
+    if (!z_prev || !bn_prev || !bs_partial) BDN_FAIL(BDN_E_ARG, "conv3x3_dgrad_bs: null pointer");
+    return conv3x3_impl(dtype, dz, C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group, w_dgrad, nullptr, dA, bs_partial,
+                        z_prev, bn_prev, N, H, W, Cout, stream);
 }

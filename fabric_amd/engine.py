@@ -155,6 +155,8 @@ class BiDateEngine:
         self._pack_desc = None
         self._packed_versions = None
         self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
+        self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
+        self.prof_filter = None    # only time launches of this kernel instantiation (an event pair is a ~150 us pipeline bubble)
         self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
 
@@ -177,15 +179,16 @@ class BiDateEngine:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
         return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn}>'
 
-    def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args):
-        if self.prof is None:
-            call('bdn_conv3x3', *args)
+    def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
+        name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
+        if self.prof is None or (self.prof_filter is not None and name != self.prof_filter):
+            call(fn, *args)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call('bdn_conv3x3', *args)
+        call(fn, *args)
         e1.record()
-        self.prof.append((self.conv_kernel_name(n, h, w, c0, c1, cout, ipg),
+        self.prof.append((name,
                           2.0 * n * h * w * cout * 9 * (c0 + c1), e0, e1))
 
     # ------------------------------------------------------------------ helpers
@@ -352,11 +355,18 @@ class BiDateEngine:
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if wgrad_stream else None
 
-        def bn_bwd(L, dA, ldA, n, ipg):
+        def bn_bwd(L, dA, ldA, n, ipg, fused_rows=0):
+            """BatchNorm+ReLU backward of layer L.  fused_rows > 0: the kernel that produced dA already left the
+            per-tile partial sums (sum g, sum g*z) in ws.stats, fused_rows rows per statistic group."""
             hk, wk = ws.dims[L.level - 1]
             dz = e(n, hk, wk, L.cout)
-            call('bdn_bn_bwd', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
-                 ptr(sc['bnb']), ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
+            if fused_rows:
+                call('bdn_bn_bwd_apply', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
+                     ptr(ws.stats), fused_rows, 1, ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']),
+                     ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
+            else:
+                call('bdn_bn_bwd', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
+                     ptr(sc['bnb']), ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
             return dz
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
@@ -379,14 +389,22 @@ class BiDateEngine:
                     grads[f'{L.conv}.bias'].zero_()
                 ready(keys)                          # a bucket all-reduce launched here is ordered behind this wgrad
 
-        def dgrad(L, dz, n, ipg):
+        def dgrad(L, dz, n, ipg, prev=None):
+            """Data gradient of layer L's conv.  prev = the layer whose relu(bn(z)) is this conv's input: its
+            BatchNorm-backward partial sums are then produced by the epilogue (returns rows per statistic group)."""
             hk, wk = ws.dims[L.level - 1]
             _, wd = self._weights(L, P, True)
             out = e(n, hk, wk, L.cin)
+            if prev is None or not self.fuse_bn_bwd_stats:
+                self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
+                                 self.dt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
+                                 ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
+                return out if prev is None else (out, 0)
             self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
-                             self.dt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
-                             ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
-            return out
+                             self.dt, ptr(dz), L.cout, ptr(wd), ptr(out), ptr(ws.z[prev.name]), ptr(ws.bn[prev.name]),
+                             ipg, ptr(ws.stats), n, hk, wk, L.cin, st, fn='bdn_conv3x3_dgrad_bs')
+            rows = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // (n // ipg)
+            return out, rows
 
         # ---- classifier
         L4b = by['d4b']
@@ -408,8 +426,8 @@ class BiDateEngine:
             cprev = La.cin - ck
             dzb = bn_bwd(Lb, dA_ptr, ldA, B, B)
             wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
-            dAa = dgrad(Lb, dzb, B, B)
-            dza = bn_bwd(La, ptr(dAa), La.cout, B, B)
+            dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
+            dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
             wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             dc = dgrad(La, dza, B, B)                       # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
             dcat[k] = dc
@@ -435,8 +453,8 @@ class BiDateEngine:
                  ptr(dP), ptr(dAb), B, hk, wk, ck, st)
             dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B)
             wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
-            dAa = dgrad(Lb, dzb, 2 * B, B)
-            dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B)
+            dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
+            dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
             src = ws.x0 if k == 1 else ws.pool[k]
             wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
             keep += [dAb, dzb, dAa, dza, dP]

@@ -66,6 +66,15 @@ int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 int N, int H, int W, int Cout, void* stream);
 int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group);
 
+/* Data gradient of nn.Conv2d(ci,co,3,padding=1) (autograd of models/unet_parts.py:13,16) with the BatchNorm-backward
+ * statistics of the PRODUCING layer fused into the epilogue: dz [N,H,W,C0] x rotated filter image w_dgrad ->
+ * dA [N,H,W,Cout] (gradient wrt relu(bn(z_prev))), and bs_partial [bdn_conv3x3_num_mtiles(N,H,W,Cout,ipg)][2][Cout] =
+ * per-tile sum g, sum g*z_prev with g = dA * [scale*z_prev + shift > 0] (z_prev [N,H,W,Cout], bn_prev [G][4][Cout]).
+ * Tiles are image-major, so a statistic group owns num_mtiles/G consecutive rows: feed bdn_bn_bwd_apply(raw_moment=1). */
+int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad, void* dA,
+                         const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
+                         int N, int H, int W, int Cout, void* stream);
+
 /* ---- weight gradient of the same convolution (autograd of models/unet_parts.py:13,16) ----
  * dz: [N,H,W,Cout]; inputs as in bdn_conv3x3.  partial: workspace of bdn_wgrad_workspace_bytes().
  * dw_oihw: f32 [Cout,Cin_real,3,3] (overwritten; channels >= Cin_real of a padded input are dropped). */
@@ -100,6 +109,15 @@ size_t bdn_bn_bwd_workspace_bytes(int dtype, int N, int H, int W, int C, int img
 int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* bn,
                int imgs_per_group, int N, int H, int W, int C,
                float* ws, float* sums, float* dgamma, float* dbeta, void* dz, void* stream);
+
+/* Second half of bdn_bn_bwd for callers whose dA producer already emitted the per-tile partial sums (fused
+ * BatchNorm-backward statistics): partial is [G][rows_per_group][2][C] holding sum_p g and, with raw_moment != 0,
+ * sum_p g*z (converted to sum_p g*xhat in double here), with g = dA * [relu(bn(z)) > 0].  Runs the fixed-order
+ * reduction (dgamma, dbeta, sums) and the dz pass; no workspace. */
+int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const float* bn,
+                     int imgs_per_group, int N, int H, int W, int C,
+                     const float* partial, int rows_per_group, int raw_moment,
+                     float* sums, float* dgamma, float* dbeta, void* dz, void* stream);
 
 /* ---- nn.MaxPool2d(2) on relu(bn(z)): models/unet_parts.py:40 (floor mode) ---- */
 int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_group,

@@ -418,3 +418,59 @@ def test_sgd_step():
     _lib.call('bdn_sgd_step', pd.data_ptr(), gd.data_ptr(), 1e-3, 0.5, n, st())
     torch.cuda.synchronize()
     assert torch.allclose(pd.cpu(), p - 1e-3 * 0.5 * g, atol=1e-6, rtol=0)
+
+
+# ------------------------------------------------------------------ fused BatchNorm-backward statistics
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [(4, 16, 16, 128, 64, 2), (6, 24, 40, 64, 128, 3), (4, 8, 8, 64, 64, 2), (2, 20, 18, 256, 128, 2),
+                                  (2, 33, 17, 64, 64, 1)])
+def test_dgrad_with_fused_bn_bwd_stats(prec, case):
+    """bdn_conv3x3_dgrad_bs + bdn_bn_bwd_apply == bdn_conv3x3 (data gradient) + bdn_bn_bwd: identical dA, and
+    dgamma / dbeta / dz equal up to the summation order of the partial sums."""
+    N, H, W, Cz, Cout, ipg = case           # dz has Cz channels; the data gradient has Cout channels (= producing layer's width)
+    dt, td = DT[prec]
+    G = N // ipg
+    lib = _lib.load()
+    dzin = to_nhwc(prec, rnd(prec, _rand((N, Cz, H, W), 51)))
+    wrot = rnd(prec, _rand((Cout, Cz, 3, 3), 52, 0.05))          # any filter: the test is about the epilogue
+    wf, _ = pack_w(prec, wrot, Cz)
+    zprev = rnd(prec, _rand((N, Cout, H, W), 53))
+    z_d = to_nhwc(prec, zprev)
+    bn = bn_table(G, Cout, 7)
+    for g in range(G):                                           # statistics of zprev itself so masks are mixed
+        zg = zprev[g * ipg:(g + 1) * ipg].double()
+        mean, var = zg.mean((0, 2, 3)), zg.var((0, 2, 3), unbiased=False)
+        inv = 1 / torch.sqrt(var + 1e-5)
+        gamma = bn[g, 2].double() / bn[g, 1].double()
+        bn[g, 0], bn[g, 1] = mean.float(), inv.float()
+        bn[g, 2] = (gamma * inv).float()
+        bn[g, 3] = (0.1 - mean * gamma * inv).float()
+    bn_d = dev(bn)
+    # reference path: plain data gradient, then the three-kernel BatchNorm backward
+    dA_ref = torch.empty(N, H, W, Cout, dtype=td, device='cuda')
+    _lib.call('bdn_conv3x3', dt, dzin.data_ptr(), Cz, None, 0, 0, None, ipg, wf.data_ptr(), None, dA_ref.data_ptr(), None,
+              N, H, W, Cout, st())
+    wsb = torch.empty(lib.bdn_bn_bwd_workspace_bytes(dt, N, H, W, Cout, ipg) // 4, device='cuda')
+    sums_r = torch.empty(G, 2, Cout, device='cuda')
+    dg_r, db_r = torch.empty(Cout, device='cuda'), torch.empty(Cout, device='cuda')
+    dz_r = torch.empty(N, H, W, Cout, dtype=td, device='cuda')
+    _lib.call('bdn_bn_bwd', dt, dA_ref.data_ptr(), Cout, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, Cout,
+              wsb.data_ptr(), sums_r.data_ptr(), dg_r.data_ptr(), db_r.data_ptr(), dz_r.data_ptr(), st())
+    # fused path
+    nt = lib.bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
+    assert nt % G == 0
+    part = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    dA = torch.empty_like(dA_ref)
+    _lib.call('bdn_conv3x3_dgrad_bs', dt, dzin.data_ptr(), Cz, wf.data_ptr(), dA.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(),
+              ipg, part.data_ptr(), N, H, W, Cout, st())
+    sums = torch.empty(G, 2, Cout, device='cuda')
+    dg, db = torch.empty(Cout, device='cuda'), torch.empty(Cout, device='cuda')
+    dz = torch.empty_like(dz_r)
+    _lib.call('bdn_bn_bwd_apply', dt, dA.data_ptr(), Cout, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, Cout,
+              part.data_ptr(), nt // G, 1, sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz.data_ptr(), st())
+    torch.cuda.synchronize()
+    assert torch.equal(dA, dA_ref)
+    assert torch.isfinite(part).all()
+    assert_close('dbeta', db.cpu(), db_r.cpu(), 2e-5)
+    assert_close('dgamma', dg.cpu(), dg_r.cpu(), 2e-5, abs_floor=2e-4)
+    assert_close('dz', dz.float().cpu(), dz_r.float().cpu(), 8e-3 if prec == 'bf16' else 2e-5)
