@@ -85,8 +85,11 @@ struct ConvCfg {
     }
 };
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+// ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
+// blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
+// is compiled for three blocks per CU instead of two.
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
+__global__ __launch_bounds__(256, ONE ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
@@ -118,14 +121,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 
     // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
     int p_pix[NPU];                                      // global pixel index of each unit (-1 = zero padding)
+    {
+        // unit i of a thread is patch pixel tid/UPP + i*(256/UPP): walk (ti, yy, xx) incrementally instead of
+        // dividing per unit (the divisions were a quarter of the prologue of the single-chunk layers)
+        constexpr int STEP = 256 / UPP, DX = STEP % TL::PW, DY = STEP / TL::PW;
+        static_assert(256 % UPP == 0, "incremental patch walk");
+        constexpr int YWRAPS = (DY + 1) / TL::PH + 1;        // upper bound on row wraps per step
+        const int pix0 = tid / UPP;
+        int xx = pix0 % TL::PW, t0 = pix0 / TL::PW, yy = t0 % TL::PH, ti = t0 / TL::PH;
 #pragma unroll
-    for (int i = 0; i < NPU; i++) {
-        const int u = tid + i * 256;
-        const int pix = u / UPP, sub = u % UPP;
-        const int xx = pix % TL::PW, t = pix / TL::PW, yy = t % TL::PH, ti = t / TL::PH;
-        const int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
-        const bool ok = u < TL::NPIX * UPP && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
+        for (int i = 0; i < NPU; i++) {
+            const int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
+            const bool ok = ti < TI && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
+            xx += DX; yy += DY;
+            if (xx >= TL::PW) { xx -= TL::PW; yy += 1; }
+#pragma unroll
+            for (int k = 0; k < YWRAPS; k++) if (yy >= TL::PH) { yy -= TL::PH; ti += 1; }
+        }
     }
     const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
     uint4 preg[NPU];
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     int chunk = 0;
     for (int c0 = 0; c0 < Cin; c0 += CK, chunk++) {
         const unsigned char* pcur = smem + (PBUF == 2 ? (chunk & 1) : 0) * CF::PATCH_BYTES;
-        const bool more = c0 + CK < Cin;
+        const bool more = ONE ? false : (c0 + CK < Cin);
         const int rec0 = chunk * KG;                     // record offset of this chunk inside a (cout block, tap) row
         A_LOAD(ae, 0)
         STEP3(0) STEP3(3) STEP3(6)
@@ -272,31 +285,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     float* red = reinterpret_cast<float*>(smem + CF::BM * CF::OSTR);
     const bool do_stats = a.stats_partial != nullptr && a.bs_z == nullptr;
     const bool full_tile = (n0 + TI <= a.N) && (y0 + TH <= a.H) && (x0 + TW <= a.W);   // block-uniform
-#pragma unroll
-    for (int nj = 0; nj < NJ; nj++) {
-        const int col = (wn * NJ + nj) * 32 + l31;
-        const float bias = a.bias ? a.bias[col0 + col] : 0.f;
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int slot = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                bool valid = true;
-                if (!full_tile) {
-                    int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
-                    valid = (n0 + ti < a.N) && (y0 + py < a.H) && (x0 + px < a.W);
-                }
-                const float v = acc[mi][nj][r] + bias;
-                if (valid) { s += v; q += v * v; }
-                *reinterpret_cast<T*>(otile + slot * CF::OSTR + col * CF::ES) = from_f<T>(v);
-            }
-        }
-        if (do_stats) {
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (half == 0) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
-        }
+    // Three block-uniform variants of the accumulator -> LDS pass, so the common cases carry no dead work:
+    //   plain (data gradient: no bias, no statistics), full tile with statistics, ragged tile with statistics.
+    // LDS addresses are one per-lane base + compile-time offsets (folded into the ds_write immediates).
+#define EPI_PASS(STATS_, RAGGED_)                                                                         \
+    _Pragma("unroll") for (int nj = 0; nj < NJ; nj++) {                                                   \
+        const int col = (wn * NJ + nj) * 32 + l31;                                                       \
+        unsigned char* ob_ = otile + (wm * MI * 32 + 4 * half) * CF::OSTR + col * CF::ES;                \
+        const float bias = (STATS_) && a.bias ? a.bias[col0 + col] : 0.f;                                \
+        float s = 0.f, q = 0.f;                                                                          \
+        _Pragma("unroll") for (int mi = 0; mi < MI; mi++) {                                               \
+            _Pragma("unroll") for (int r = 0; r < 16; r++) {                                              \
+                constexpr int dummy_ = 0; (void)dummy_;                                                  \
+                const int srel_ = mi * 32 + (r & 3) + 8 * (r >> 2);            /* slot - (wm*MI*32 + 4*half) */ \
+                float v = acc[mi][nj][r];                                                                \
+                if (STATS_) {                                                                            \
+                    v += bias;                                                                           \
+                    bool valid = true;                                                                   \
+                    if (RAGGED_) {                                                                       \
+                        int ti, py, px; TL::slot_to_nyx((wm * MI) * 32 + 4 * half + srel_, ti, py, px);  \
+                        valid = (n0 + ti < a.N) && (y0 + py < a.H) && (x0 + px < a.W);                   \
+                    }                                                                                    \
+                    if (valid) { s += v; q = fmaf(v, v, q); }                                            \
+                }                                                                                        \
+                *reinterpret_cast<T*>(ob_ + srel_ * CF::OSTR) = from_f<T>(v);                            \
+            }                                                                                            \
+        }                                                                                                \
+        if (STATS_) {                                                                                    \
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);                                              \
+            if (half == 0) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }           \
+        }                                                                                                \
     }
+    if (!do_stats && a.bias == nullptr) { EPI_PASS(false, false) }
+    else if (full_tile) { EPI_PASS(true, false) }
+    else { EPI_PASS(true, true) }
+#undef EPI_PASS
     __syncthreads();
     if (do_stats && tid < BN) {
         float s = 0.f, q = 0.f;
@@ -366,10 +389,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     }
 }
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN>;
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
@@ -418,6 +441,10 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 #ifdef NARROW_22
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
 #else
+    const bool one = (a.C0 + a.C1) * (int)sizeof(T) == CKB;
+#ifndef NO_ONE
+    if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1, true>(a, g.n_mtiles, st);
+#endif
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
 #endif
     if (g.TI == 1) {

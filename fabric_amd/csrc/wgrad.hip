@@ -484,6 +484,7 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
     }
 }
 
+static int g_wgrad_blocks = 256;      // bdn_set_tuning(BDN_TUNE_WGRAD_BLOCKS): target grid size of the weight-gradient GEMM
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; };
 static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
     WgPlan p;
@@ -491,7 +492,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
     p.n_cot = Cout / 64;
     p.n_cit = (Cin + 63) / 64;
     const int tiles = p.n_cot * p.n_cit;
-    int S = (256 + tiles - 1) / tiles;                      // ~256 blocks: the kernel runs beside the dgrad chain on a second stream, so
+    int S = (g_wgrad_blocks + tiles - 1) / tiles;                      // ~256 blocks: the kernel runs beside the dgrad chain on a second stream, so
                                                             // a smaller partial-sum footprint beats more parallelism (A/B: 512 -> 256 = -2.7 % step)
     if (S > p.g.n_mtiles) S = p.g.n_mtiles;
     if (S < 1) S = 1;
@@ -499,6 +500,11 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
     p.S = (p.g.n_mtiles + p.per_split - 1) / p.per_split;   // no empty splits
     p.ksplit = Cin <= 32;
     return p;
+}
+
+extern "C" int bdn_set_tuning(int key, int value) {
+    if (key == BDN_TUNE_WGRAD_BLOCKS && value >= 1 && value <= 4096) { g_wgrad_blocks = value; return BDN_OK; }
+    BDN_FAIL(BDN_E_ARG, "set_tuning: unknown key %d or value %d out of range", key, value);
 }
 
 extern "C" size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {

@@ -156,6 +156,8 @@ class BiDateEngine:
         self._packed_versions = None
         self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
+        self._diag_skip_wgrad = False
+        self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
         self.prof_filter = None    # only time launches of this kernel instantiation (an event pair is a ~150 us pipeline bubble)
         self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
@@ -177,7 +179,8 @@ class BiDateEngine:
             t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
         else:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
-        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn}>'
+        one = ',one' if th == 16 and (c0 + c1) * self.esize == ckb else ''      # single-chunk variant (3 blocks per CU)
+        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn}{one}>'
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
         name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
@@ -370,6 +373,8 @@ class BiDateEngine:
             return dz
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
+            if self._diag_skip_wgrad:                # tools/ab_step.py diagnostic only: how long is the dz chain alone?
+                return
             hk, wk = ws.dims[L.level - 1]
             keys = [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias']
             if side is None:
@@ -424,12 +429,19 @@ class BiDateEngine:
             La, Lb = by[f'd{j}a'], by[f'd{j}b']
             ck = ENC_CH[k - 1]
             cprev = La.cin - ck
+            late = self.wgrad_after_dgrad
             dzb = bn_bwd(Lb, dA_ptr, ldA, B, B)
-            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
+            if not late:
+                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
+            if late:
+                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
-            wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
+            if not late:
+                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             dc = dgrad(La, dza, B, B)                       # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
+            if late:
+                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             dcat[k] = dc
             dprev = e(B, hs, wsrc, cprev)
             call('bdn_upsample2x_bwd', self.dt, dc.data_ptr() + ck * es, La.cin, ptr(dprev), B, hs, wsrc, hk, wk, cprev, st)
@@ -440,6 +452,7 @@ class BiDateEngine:
                 dF5 = dprev
         # ---- encoder (both dates at once)
         dP = None
+        late = self.wgrad_after_dgrad
         for k in range(5, 0, -1):
             hk, wk = ws.dims[k - 1]
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
@@ -452,13 +465,19 @@ class BiDateEngine:
             call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
                  ptr(dP), ptr(dAb), B, hk, wk, ck, st)
             dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B)
-            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
+            if not late:
+                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
             dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
+            if late:
+                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
             dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
             src = ws.x0 if k == 1 else ws.pool[k]
-            wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
+            if not late:
+                wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
             keep += [dAb, dzb, dAa, dza, dP]
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
+            if late:
+                wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
         if side is not None:
             main.wait_stream(side)                   # every weight gradient is complete before the caller's next kernel
         return grads

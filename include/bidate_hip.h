@@ -50,6 +50,12 @@ int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
  * { const float* w_oihw; void* wf; void* wd; int32 Cout, Cin, Cin_pad, reserved; } (40 bytes each). */
 int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stream);
 
+/* Tuning knobs (process-wide, not part of the numerical contract; results stay deterministic for a fixed setting).
+ * BDN_TUNE_WGRAD_BLOCKS: target number of blocks of the weight-gradient GEMM (default 256 = one per CU); changes
+ * bdn_wgrad_workspace_bytes, so set it before sizing workspaces. */
+#define BDN_TUNE_WGRAD_BLOCKS 1
+int bdn_set_tuning(int key, int value);
+
 /* ---- 3x3 convolution, stride 1, zero padding 1: nn.Conv2d(ci,co,3,padding=1), models/unet_parts.py:13,16 ----
  * Implicit GEMM on MFMA.  The A operand is gathered from in0 (channels [0,C0)) and optionally in1
  * (channels [C0,C0+C1), the never-materialised torch.cat of models/unet_parts.py:78).
