@@ -89,7 +89,9 @@ struct ConvCfg {
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
-__global__ __launch_bounds__(256, ONE ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+// blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
+// (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
+__global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
