@@ -34,13 +34,15 @@ SIGNATURES = {
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_enc_skip_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_outc_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_set_tuning': (_i, [_i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    'bdn_bn_bwd_apply': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),
+    'bdn_bn_bwd_apply': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_overlap_loss': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_focal_workspace_bytes': (_sz, []),
     'bdn_focal': (_i, [_vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

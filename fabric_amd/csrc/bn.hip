@@ -255,6 +255,48 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
+// Second stage for many partial rows (> BNB_DIRECT_ROWS per group): rows were pre-reduced by reduce_rows_kernel into
+// part2[g][RS][2][C] doubles; one thread per channel finishes in a fixed order.
+__global__ void bn_bwd_finalize_part2_kernel(const double* __restrict__ part2, int RS, int G, int C,
+                                             float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                             const float* __restrict__ raw_bn) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t0 = 0.0, t1 = 0.0;
+    for (int g = 0; g < G; g++) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int s = 0; s < RS; s++) {
+            a0 += part2[(((size_t)g * RS + s) * 2 + 0) * C + c];
+            a1 += part2[(((size_t)g * RS + s) * 2 + 1) * C + c];
+        }
+        if (raw_bn) a1 = (double)bn_row(raw_bn, g, 1, C)[c] * (a1 - (double)bn_row(raw_bn, g, 0, C)[c] * a0);
+        sums[((size_t)g * 2 + 0) * C + c] = (float)a0;
+        sums[((size_t)g * 2 + 1) * C + c] = (float)a1;
+        t0 += a0; t1 += a1;
+    }
+    if (dbeta) dbeta[c] = (float)t0;
+    if (dgamma) dgamma[c] = (float)t1;
+}
+
+constexpr int BNB_DIRECT_ROWS = 512;   // above this many partial rows per group the reduction is split over blocks first
+
+// partial rows -> sums / dgamma / dbeta.  ws2: bdn_bn_bwd_scratch_bytes(G, C) bytes (doubles), used only for many rows.
+static void launch_bn_bwd_finalize(const float* partial, int rows_per_group, int G, int C, float* sums, float* dgamma, float* dbeta,
+                                   const float* raw_bn, void* ws2, hipStream_t st) {
+    if (rows_per_group <= BNB_DIRECT_ROWS || ws2 == nullptr) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partial, rows_per_group, G, C, sums, dgamma, dbeta, raw_bn);
+        return;
+    }
+    const RowPlan p = row_plan(rows_per_group);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64, G, p.RS), dim3(256), 0, st, partial, rows_per_group, p.rps, p.RS, C, (double*)ws2);
+    hipLaunchKernelGGL(bn_bwd_finalize_part2_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const double*)ws2, p.RS, G, C, sums, dgamma, dbeta, raw_bn);
+}
+
+extern "C" size_t bdn_bn_bwd_scratch_bytes(int G, int C) {
+    if (G <= 0 || C <= 0) return 0;
+    return (size_t)G * 64 * 2 * C * sizeof(double);
+}
+
 // dz = scale * (g - s0/M - xhat * s1/M)
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
@@ -296,13 +338,15 @@ static inline int bnb_pix_per_block(int pix_per_group, int rows) {
     return (p + rows - 1) / rows * rows;
 }
 
+static inline size_t bnb_partial_bytes(size_t blocks, int C) { return (blocks * 2 * C * sizeof(float) + 255) / 256 * 256; }
+
 extern "C" size_t bdn_bn_bwd_workspace_bytes(int dtype, int N, int H, int W, int C, int imgs_per_group) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || imgs_per_group <= 0 || C % 16 || C > 1024) return 0;
     const int epu = dtype == BDN_BF16 ? 8 : 4;
     const int ppg = imgs_per_group * H * W;
     const int ppb = bnb_pix_per_block(ppg, 256 / (C / epu));
     const size_t blocks = (size_t)(N / imgs_per_group) * ((ppg + ppb - 1) / ppb);
-    return blocks * 2 * C * sizeof(float);
+    return bnb_partial_bytes(blocks, C) + bdn_bn_bwd_scratch_bytes(N / imgs_per_group, C);
 }
 
 template <typename T>
@@ -316,7 +360,8 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(G * bpg), dim3(256), 256 * EPU * 2 * sizeof(float), st,
                        (const T*)dA, ldA, (const T*)z, bn, ppg, bpg, ppb, C, ws);
     BDN_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, ws, bpg, G, C, sums, dgamma, dbeta, (const float*)nullptr);
+    launch_bn_bwd_finalize(ws, bpg, G, C, sums, dgamma, dbeta, nullptr,
+                           reinterpret_cast<unsigned char*>(ws) + bnb_partial_bytes((size_t)G * bpg, C), st);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
                        (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
@@ -327,14 +372,13 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
 template <typename T>
 static int bn_bwd_apply_impl(const void* dA, int ldA, const void* z, const float* bn, int imgs_per_group,
                              int N, int H, int W, int C, const float* partial, int rows_per_group, int raw_moment,
-                             float* sums, float* dgamma, float* dbeta, void* dz, hipStream_t st) {
+                             float* sums, float* dgamma, float* dbeta, void* dz, void* scratch, hipStream_t st) {
     constexpr int EPU = ET<T>::EPU;
     const int G = N / imgs_per_group;
     const int ppg = imgs_per_group * H * W;
     const int ppb = bnb_pix_per_block(ppg, 256 / (C / EPU));
     const int bpg = (ppg + ppb - 1) / ppb;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partial, rows_per_group, G, C, sums, dgamma, dbeta,
-                       raw_moment ? bn : (const float*)nullptr);
+    launch_bn_bwd_finalize(partial, rows_per_group, G, C, sums, dgamma, dbeta, raw_moment ? bn : (const float*)nullptr, scratch, st);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
                        (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
@@ -345,13 +389,13 @@ static int bn_bwd_apply_impl(const void* dA, int ldA, const void* z, const float
 extern "C" int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const float* bn,
                                 int imgs_per_group, int N, int H, int W, int C,
                                 const float* partial, int rows_per_group, int raw_moment,
-                                float* sums, float* dgamma, float* dbeta, void* dz, void* stream) {
+                                float* sums, float* dgamma, float* dbeta, void* dz, void* scratch, void* stream) {
     if (!dA || !z || !bn || !partial || !sums || !dz) BDN_FAIL(BDN_E_ARG, "bn_bwd_apply: null pointer");
     if (N <= 0 || imgs_per_group <= 0 || N % imgs_per_group || C % 16 || ldA < C || ldA % 16 || rows_per_group <= 0)
         BDN_FAIL(BDN_E_SHAPE, "bn_bwd_apply: bad shape");
     if (C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "bn_bwd_apply: C=%d must divide 1024", C);
-    if (dtype == BDN_BF16) return bn_bwd_apply_impl<bf16s>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, (hipStream_t)stream);
-    if (dtype == BDN_F32) return bn_bwd_apply_impl<float>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, (hipStream_t)stream);
+    if (dtype == BDN_BF16) return bn_bwd_apply_impl<bf16s>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, scratch, (hipStream_t)stream);
+    if (dtype == BDN_F32) return bn_bwd_apply_impl<float>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, scratch, (hipStream_t)stream);
     BDN_FAIL(BDN_E_ARG, "bn_bwd_apply: bad dtype");
 }
 

@@ -216,84 +216,132 @@ extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc
 }
 
 // ============================================================ backward of product fusion + max-pool into encoder outputs
-// one loop iteration = one 2x2 window x EPU channels x both dates
+// one loop iteration = one 2x2 window x EPU channels x both dates.  Two passes over the window: the first finds,
+// per channel and date, WHICH position holds the (first) maximum; the second re-reads z (cache hits), forms the
+// gradients and -- when bs_partial is given -- also the BatchNorm-backward partial sums of the layer (sum g,
+// sum g*z with g = dA * [relu(bn(z)) > 0], on the STORED, rounded dA), so no separate reduction pass reads dA and z.
 template <typename T>
 __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
-                                    const T* __restrict__ dP, T* __restrict__ dA, int B, int H, int W, int C, int ncell) {
+                                    const T* __restrict__ dP, T* __restrict__ dA, float* __restrict__ bs_partial,
+                                    int B, int H, int W, int C, int ncell) {
     constexpr int EPU = ET<T>::EPU;
+    extern __shared__ float sred[];                            // [256][EPU][4] when bs_partial
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
     float sc0[EPU], sh0[EPU], sc1[EPU], sh1[EPU];
     load_consts<T>(bn_row(bn, 0, 2, C) + c, sc0); load_consts<T>(bn_row(bn, 0, 3, C) + c, sh0);
     load_consts<T>(bn_row(bn, 1, 2, C) + c, sc1); load_consts<T>(bn_row(bn, 1, 3, C) + c, sh1);
+    float t00[EPU], t01[EPU], t10[EPU], t11[EPU];              // [date][sum g | sum g*z]
+#pragma unroll
+    for (int i = 0; i < EPU; i++) { t00[i] = 0.f; t01[i] = 0.f; t10[i] = 0.f; t11[i] = 0.f; }
+    const bool bs = bs_partial != nullptr;
     constexpr int IT = 4;
     const int q_end = min(ncell, (int)(blockIdx.x + 1) * rows * IT);
     for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
         const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
         const bool pooled = dP != nullptr && yc < Ho && xc < Wo;   // floor-mode pooling leaves a trailing odd row/col unpooled
-        float a0[4][EPU], a1[4][EPU];                              // activations of date 1 / date 2 at the 4 window positions
+        // ---- pass 1: position of the FIRST maximum of each window (strict >, like ATen's max_pool2d)
+        unsigned idx0 = 0, idx1 = 0;                               // 2 bits per channel
+        if (pooled) {
+            float m0[EPU], m1[EPU];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-            const bool ok = y < H && x < W;
-            float f0[EPU], f1[EPU];
-            if (ok) {
+            for (int i = 0; i < EPU; i++) { m0[i] = -1.f; m1[i] = -1.f; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);      // pooled windows are complete
+                float f0[EPU], f1[EPU];
                 Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)(b * H + y) * W + x) * C + c), f0);
                 Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)((B + b) * H + y) * W + x) * C + c), f1);
-            }
 #pragma unroll
-            for (int i = 0; i < EPU; i++) {
-                a0[k][i] = ok ? act1<T>(f0[i], sc0[i], sh0[i]) : 0.f;
-                a1[k][i] = ok ? act1<T>(f1[i], sc1[i], sh1[i]) : 0.f;
+                for (int i = 0; i < EPU; i++) {
+                    const float a0 = act1<T>(f0[i], sc0[i], sh0[i]), a1 = act1<T>(f1[i], sc1[i], sh1[i]);
+                    if (a0 > m0[i]) { m0[i] = a0; idx0 = (idx0 & ~(3u << (2 * i))) | ((unsigned)k << (2 * i)); }
+                    if (a1 > m1[i]) { m1[i] = a1; idx1 = (idx1 & ~(3u << (2 * i))) | ((unsigned)k << (2 * i)); }
+                }
             }
         }
         float g0[EPU], g1[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) { g0[i] = 0.f; g1[i] = 0.f; }
         if (pooled) {
             Unit<T>::unpack(*reinterpret_cast<const uint4*>(dP + ((size_t)(b * Ho + yc) * Wo + xc) * C + c), g0);
             Unit<T>::unpack(*reinterpret_cast<const uint4*>(dP + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c), g1);
         }
-        // route the pooled gradient to the FIRST maximum of each window (strict >, like ATen's max_pool2d)
-        float m0[EPU], m1[EPU];
-#pragma unroll
-        for (int i = 0; i < EPU; i++) {
-            m0[i] = fmaxf(fmaxf(a0[0][i], a0[1][i]), fmaxf(a0[2][i], a0[3][i]));
-            m1[i] = fmaxf(fmaxf(a1[0][i], a1[1][i]), fmaxf(a1[2][i], a1[3][i]));
-        }
-        bool done0[EPU], done1[EPU];
-#pragma unroll
-        for (int i = 0; i < EPU; i++) { done0[i] = !pooled; done1[i] = !pooled; }
+        // ---- pass 2: gradients (and statistics)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-            const bool ok = y < H && x < W;
-            float df[EPU], o0[EPU], o1[EPU];
-            if (ok) Unit<T>::unpack(*reinterpret_cast<const uint4*>(dF + ((size_t)(b * H + y) * W + x) * ldF + c), df);
+            if (y < H && x < W) {
+                float f0[EPU], f1[EPU], df[EPU], o0[EPU], o1[EPU];
+                const size_t p0 = ((size_t)(b * H + y) * W + x), p1 = ((size_t)((B + b) * H + y) * W + x);
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p0 * C + c), f0);
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p1 * C + c), f1);
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(dF + p0 * ldF + c), df);
 #pragma unroll
-            for (int i = 0; i < EPU; i++) {
-                const float d = ok ? df[i] : 0.f;
-                o0[i] = d * a1[k][i];
-                o1[i] = d * a0[k][i];
-                if (!done0[i] && a0[k][i] == m0[i]) { o0[i] += g0[i]; done0[i] = true; }
-                if (!done1[i] && a1[k][i] == m1[i]) { o1[i] += g1[i]; done1[i] = true; }
+                for (int i = 0; i < EPU; i++) {
+                    const float a0 = act1<T>(f0[i], sc0[i], sh0[i]), a1 = act1<T>(f1[i], sc1[i], sh1[i]);
+                    o0[i] = df[i] * a1;
+                    o1[i] = df[i] * a0;
+                    if (pooled && ((idx0 >> (2 * i)) & 3u) == (unsigned)k) o0[i] += g0[i];
+                    if (pooled && ((idx1 >> (2 * i)) & 3u) == (unsigned)k) o1[i] += g1[i];
+                }
+                const uint4 u0 = Unit<T>::pack(o0), u1 = Unit<T>::pack(o1);
+                *reinterpret_cast<uint4*>(dA + p0 * C + c) = u0;
+                *reinterpret_cast<uint4*>(dA + p1 * C + c) = u1;
+                if (bs) {
+                    Unit<T>::unpack(u0, o0); Unit<T>::unpack(u1, o1);       // what BatchNorm backward will read back
+#pragma unroll
+                    for (int i = 0; i < EPU; i++) {
+                        const float m0 = fmaf(f0[i], sc0[i], sh0[i]) > 0.f ? o0[i] : 0.f;
+                        const float m1 = fmaf(f1[i], sc1[i], sh1[i]) > 0.f ? o1[i] : 0.f;
+                        t00[i] += m0; t01[i] = fmaf(m0, f0[i], t01[i]);
+                        t10[i] += m1; t11[i] = fmaf(m1, f1[i], t11[i]);
+                    }
+                }
             }
-            if (ok) {
-                *reinterpret_cast<uint4*>(dA + ((size_t)(b * H + y) * W + x) * C + c) = Unit<T>::pack(o0);
-                *reinterpret_cast<uint4*>(dA + ((size_t)((B + b) * H + y) * W + x) * C + c) = Unit<T>::pack(o1);
-            }
+        }
+    }
+    if (bs) {
+        // bs_partial[date][block][2][C]: rows lanes of one channel unit meet in LDS, fixed order
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            sred[(tid * EPU + i) * 4 + 0] = t00[i]; sred[(tid * EPU + i) * 4 + 1] = t01[i];
+            sred[(tid * EPU + i) * 4 + 2] = t10[i]; sred[(tid * EPU + i) * 4 + 3] = t11[i];
+        }
+        __syncthreads();
+        for (int o = tid; o < C * 4; o += 256) {
+            const int k = o & 3, cc = o >> 2, ccu = cc / EPU, i = cc % EPU;
+            float v = 0.f;
+            for (int r = 0; r < rows; r++) v += sred[((r * CU + ccu) * EPU + i) * 4 + k];
+            bs_partial[(((size_t)(k >> 1) * gridDim.x + blockIdx.x) * 2 + (k & 1)) * C + cc] = v;
         }
     }
 }
 
+static inline int enc_skip_bwd_blocks(int dtype, int B, int H, int W, int C) {
+    const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
+    const int per = 256 / (C / (dtype == BDN_BF16 ? 8 : 4)) * 4;
+    return (ncell + per - 1) / per;
+}
+
+extern "C" int bdn_enc_skip_bwd_rows(int dtype, int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 16 || C > 1024 || 1024 % C) return 0;
+    return enc_skip_bwd_blocks(dtype, B, H, W, C);
+}
+
 extern "C" int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const float* bn,
-                                const void* dP, void* dA, int B, int H, int W, int C, void* stream) {
+                                const void* dP, void* dA, float* bs_partial, int B, int H, int W, int C, void* stream) {
     if (!dF || !z || !bn || !dA) BDN_FAIL(BDN_E_ARG, "enc_skip_bwd: null pointer");
     if (C % 16 || C > 1024 || 1024 % C || ldF < C || ldF % 16) BDN_FAIL(BDN_E_SHAPE, "enc_skip_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
-    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
-        hipLaunchKernelGGL(enc_skip_bwd_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, B, H, W, C, ncell); }
-    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
-        hipLaunchKernelGGL(enc_skip_bwd_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, B, H, W, C, ncell); }
+    const int grid = enc_skip_bwd_blocks(dtype, B, H, W, C);
+    if (dtype == BDN_BF16)
+        hipLaunchKernelGGL(enc_skip_bwd_kernel<bf16s>, dim3(grid), dim3(256), bs_partial ? 256 * 8 * 4 * sizeof(float) : 0, st,
+                           (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, bs_partial, B, H, W, C, ncell);
+    else if (dtype == BDN_F32)
+        hipLaunchKernelGGL(enc_skip_bwd_kernel<float>, dim3(grid), dim3(256), bs_partial ? 256 * 4 * 4 * sizeof(float) : 0, st,
+                           (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, bs_partial, B, H, W, C, ncell);
     else BDN_FAIL(BDN_E_ARG, "enc_skip_bwd: bad dtype");
     BDN_CHECK_LAUNCH("enc_skip_bwd");
     return BDN_OK;

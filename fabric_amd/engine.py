@@ -117,6 +117,8 @@ class Workspace:
             hk, wk = self.dims[L.level - 1]
             n, ipg = (2 * B, B) if L.enc else (B, B)
             n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg) * 2 * L.cout)
+            if L.enc:                                 # enc_skip_bwd leaves its BatchNorm-backward partials here too
+                n_stats = max(n_stats, 2 * lib.bdn_enc_skip_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(eng.dt, n, hk, wk, L.cout, ipg) // 4)
             n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes(n, hk, wk, L.cout, L.cin, ipg) // 4)
         self.stats = f32(n_stats)
@@ -366,7 +368,7 @@ class BiDateEngine:
             if fused_rows:
                 call('bdn_bn_bwd_apply', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
                      ptr(ws.stats), fused_rows, 1, ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']),
-                     ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
+                     ptr(grads[f'{L.bn}.bias']), ptr(dz), ptr(ws.bnws), st)
             else:
                 call('bdn_bn_bwd', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
                      ptr(sc['bnb']), ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
@@ -462,9 +464,11 @@ class BiDateEngine:
             else:
                 dF_ptr, ldF = ptr(dcat[k]), dcat[k].shape[3]
             dAb = e(2 * B, hk, wk, ck)
+            fuse = self.fuse_bn_bwd_stats
             call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
-                 ptr(dP), ptr(dAb), B, hk, wk, ck, st)
-            dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B)
+                 ptr(dP), ptr(dAb), ptr(ws.stats) if fuse else None, B, hk, wk, ck, st)
+            rows_b = _lib.load().bdn_enc_skip_bwd_rows(self.dt, B, hk, wk, ck) if fuse else 0
+            dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
             if not late:
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
             dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)

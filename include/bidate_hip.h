@@ -119,11 +119,13 @@ int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* b
 /* Second half of bdn_bn_bwd for callers whose dA producer already emitted the per-tile partial sums (fused
  * BatchNorm-backward statistics): partial is [G][rows_per_group][2][C] holding sum_p g and, with raw_moment != 0,
  * sum_p g*z (converted to sum_p g*xhat in double here), with g = dA * [relu(bn(z)) > 0].  Runs the fixed-order
- * reduction (dgamma, dbeta, sums) and the dz pass; no workspace. */
+ * reduction (dgamma, dbeta, sums) and the dz pass.  scratch: NULL or bdn_bn_bwd_scratch_bytes(G, C) bytes; with it,
+ * more than 512 rows per group are pre-reduced by many blocks (same result, fixed order either way). */
+size_t bdn_bn_bwd_scratch_bytes(int G, int C);
 int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const float* bn,
                      int imgs_per_group, int N, int H, int W, int C,
                      const float* partial, int rows_per_group, int raw_moment,
-                     float* sums, float* dgamma, float* dbeta, void* dz, void* stream);
+                     float* sums, float* dgamma, float* dbeta, void* dz, void* scratch, void* stream);
 
 /* ---- nn.MaxPool2d(2) on relu(bn(z)): models/unet_parts.py:40 (floor mode) ---- */
 int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_group,
@@ -148,7 +150,10 @@ int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
  * pooled map; dA: [2B,H,W,C] = gradient wrt relu(bn(z)) of each date:
  * dA_d1 = dF * a_d2 + unpool(dP_d1), dA_d2 = dF * a_d1 + unpool(dP_d2)  (first maximum wins ties). */
 int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const float* bn,
-                     const void* dP, void* dA, int B, int H, int W, int C, void* stream);
+                     const void* dP, void* dA, float* bs_partial, int B, int H, int W, int C, void* stream);
+/* bs_partial: NULL, or f32 [2][bdn_enc_skip_bwd_rows(dtype,B,H,W,C)][2][C] receiving the BatchNorm-backward partial
+ * sums of the layer (per block: sum g, sum g*z; date 1 rows then date 2 rows) -> bdn_bn_bwd_apply(raw_moment = 1). */
+int bdn_enc_skip_bwd_rows(int dtype, int B, int H, int W, int C);
 
 /* ---- outconv: nn.Conv2d(64, n_classes, 1), models/unet_parts.py:86 ----
  * z: [B,H,W,C] raw output of up4's second conv, bn: [1][4][C]; w: [ncls][C] f32, b: [ncls];

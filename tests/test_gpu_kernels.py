@@ -303,9 +303,22 @@ def test_enc_skip_bwd(prec, case):
     out = torch.empty(2 * B, H, W, C, dtype=td, device='cuda')
     dF_d, z_d, bn_d = to_nhwc(prec, dF), to_nhwc(prec, z), dev(bn)
     dP_d = to_nhwc(prec, dP) if pooled else None
+    rows = _lib.load().bdn_enc_skip_bwd_rows(dt, B, H, W, C)
+    part = torch.full((2, rows, 2, C), float('nan'), device='cuda')
     _lib.call('bdn_enc_skip_bwd', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
-              dP_d.data_ptr() if pooled else None, out.data_ptr(), B, H, W, C, st())
+              dP_d.data_ptr() if pooled else None, out.data_ptr(), part.data_ptr(), B, H, W, C, st())
+    out2 = torch.empty_like(out)
+    _lib.call('bdn_enc_skip_bwd', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
+              dP_d.data_ptr() if pooled else None, out2.data_ptr(), None, B, H, W, C, st())
     torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    # fused BatchNorm-backward partial sums: sum g and sum g*z over the STORED gradient, per date
+    g = from_nhwc(out).double() * (bnrelu_ref(prec, z, bn, B) > 0)
+    for d in range(2):
+        sl = slice(d * B, (d + 1) * B)
+        got = part[d].double().sum(0).cpu()                       # [2][C]
+        assert_close(f'sum g (date {d})', got[0].float(), g[sl].sum((0, 2, 3)).float(), 2e-5, abs_floor=1e-4)
+        assert_close(f'sum g*z (date {d})', got[1].float(), (g[sl] * z[sl].double()).sum((0, 2, 3)).float(), 2e-5, abs_floor=1e-4)
     # Where a == 0 the reference's relu(a2*a1) has zero slope while the kernel returns dF*a_other; both are
     # multiplied by the producer's own ReLU mask [a > 0] in the very next step (bn_bwd), so compare there.
     live = (a.detach() > 0).float()
@@ -423,7 +436,7 @@ def test_sgd_step():
 # ------------------------------------------------------------------ fused BatchNorm-backward statistics
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('case', [(4, 16, 16, 128, 64, 2), (6, 24, 40, 64, 128, 3), (4, 8, 8, 64, 64, 2), (2, 20, 18, 256, 128, 2),
-                                  (2, 33, 17, 64, 64, 1)])
+                                  (2, 33, 17, 64, 64, 1), (8, 128, 128, 64, 64, 4)])
 def test_dgrad_with_fused_bn_bwd_stats(prec, case):
     """bdn_conv3x3_dgrad_bs + bdn_bn_bwd_apply == bdn_conv3x3 (data gradient) + bdn_bn_bwd: identical dA, and
     dgamma / dbeta / dz equal up to the summation order of the partial sums."""
@@ -466,8 +479,10 @@ def test_dgrad_with_fused_bn_bwd_stats(prec, case):
     sums = torch.empty(G, 2, Cout, device='cuda')
     dg, db = torch.empty(Cout, device='cuda'), torch.empty(Cout, device='cuda')
     dz = torch.empty_like(dz_r)
+    scratch = torch.empty(lib.bdn_bn_bwd_scratch_bytes(G, Cout), dtype=torch.uint8, device='cuda') if N * H * W > 1500 else None
     _lib.call('bdn_bn_bwd_apply', dt, dA.data_ptr(), Cout, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, Cout,
-              part.data_ptr(), nt // G, 1, sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz.data_ptr(), st())
+              part.data_ptr(), nt // G, 1, sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz.data_ptr(),
+              scratch.data_ptr() if scratch is not None else None, st())
     torch.cuda.synchronize()
     assert torch.equal(dA, dA_ref)
     assert torch.isfinite(part).all()
