@@ -167,14 +167,15 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
                                 const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ dw, float* __restrict__ db,
-                                int npix, int hw, int C, int ncls) {
+                                float* __restrict__ bs_partial, int npix, int hw, int C, int ncls) {
     constexpr int EPU = ET<T>::EPU;
-    extern __shared__ float sm[];                             // [ncls][C+1] block accumulators
+    extern __shared__ float sm[];                             // [ncls][C+1] block accumulators (+ [256][EPU][2] with bs_partial)
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     for (int i = tid; i < ncls * (C + 1); i += 256) sm[i] = 0.f;
-    float sc[EPU], sh[EPU], wk[NC][EPU], acc[NC][EPU], accb[NC];
+    float sc[EPU], sh[EPU], wk[NC][EPU], acc[NC][EPU], accb[NC], t0[EPU], t1[EPU];
 #pragma unroll
-    for (int i = 0; i < EPU; i++) { sc[i] = bn_row(bn, 0, 2, C)[c + i]; sh[i] = bn_row(bn, 0, 3, C)[c + i]; }
+    for (int i = 0; i < EPU; i++) { sc[i] = bn_row(bn, 0, 2, C)[c + i]; sh[i] = bn_row(bn, 0, 3, C)[c + i]; t0[i] = 0.f; t1[i] = 0.f; }
+    const bool bs = bs_partial != nullptr;
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         accb[k] = 0.f;
@@ -201,7 +202,16 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int k = 0; k < NC; k++) accb[k] += g[k];
         }
-        *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = Unit<T>::pack(o);
+        const uint4 uo = Unit<T>::pack(o);
+        *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
+        if (bs) {                                             // BatchNorm-backward partial sums of this layer on the stored gradient
+            Unit<T>::unpack(uo, o);
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                const float gm = fmaf(f[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
+                t0[i] += gm; t1[i] = fmaf(gm, f[i], t1[i]);
+            }
+        }
     }
     for (int k = 0; k < ncls; k++) {
 #pragma unroll
@@ -213,23 +223,42 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
         const int k = i / (C + 1), cc = i % (C + 1);
         if (cc < C) atomicAdd(&dw[k * C + cc], sm[i]); else atomicAdd(&db[k], sm[i]);
     }
+    if (bs) {                                                 // bs_partial[block][2][C], fixed order
+        float* sred = sm + ncls * (C + 1);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) { sred[(tid * EPU + i) * 2] = t0[i]; sred[(tid * EPU + i) * 2 + 1] = t1[i]; }
+        __syncthreads();
+        for (int o = tid; o < C * 2; o += 256) {
+            const int k = o & 1, cc = o >> 1, ccu = cc / EPU, i = cc % EPU;
+            float v = 0.f;
+            for (int r = 0; r < rows; r++) v += sred[((r * CU + ccu) * EPU + i) * 2 + k];
+            bs_partial[((size_t)blockIdx.x * 2 + k) * C + cc] = v;
+        }
+    }
+}
+
+extern "C" int bdn_outc_bwd_rows(int dtype, int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 16 || C > 1024 || 1024 % C) return 0;
+    const int per = 256 / (C / (dtype == BDN_BF16 ? 8 : 4)) * OUTC_ITERS;
+    return (B * H * W + per - 1) / per;
 }
 
 extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
-                            void* dA, float* dw, float* db, int B, int H, int W, int C, int ncls, void* stream) {
+                            void* dA, float* dw, float* db, float* bs_partial, int B, int H, int W, int C, int ncls, void* stream) {
     if (!dlogits || !z || !bn || !w || !dA || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
     if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream; const int npix = B * H * W;
     hipMemsetAsync(dw, 0, sizeof(float) * ncls * C, st);
     hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
-    const size_t smem = sizeof(float) * ncls * (C + 1);
-    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * OUTC_ITERS;
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, npix, H * W, C, ncls);
-        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, npix, H * W, C, ncls); }
-    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * OUTC_ITERS;
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, npix, H * W, C, ncls);
-        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3((npix + per - 1) / per), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, npix, H * W, C, ncls); }
-    else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
+    const unsigned grid = bdn_outc_bwd_rows(dtype, B, H, W, C);
+    const size_t smem = sizeof(float) * (ncls * (C + 1) + (bs_partial ? 256 * (dtype == BDN_BF16 ? 8 : 4) * 2 : 0));
+    if (dtype == BDN_BF16) {
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
+        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
+    } else if (dtype == BDN_F32) {
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
+        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
+    } else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
     return BDN_OK;
 }

@@ -117,6 +117,8 @@ class Workspace:
             hk, wk = self.dims[L.level - 1]
             n, ipg = (2 * B, B) if L.enc else (B, B)
             n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg) * 2 * L.cout)
+            if L.name == 'd4b':
+                n_stats = max(n_stats, lib.bdn_outc_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             if L.enc:                                 # enc_skip_bwd leaves its BatchNorm-backward partials here too
                 n_stats = max(n_stats, 2 * lib.bdn_enc_skip_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(eng.dt, n, hk, wk, L.cout, ipg) // 4)
@@ -416,8 +418,11 @@ class BiDateEngine:
         # ---- classifier
         L4b = by['d4b']
         dA = e(B, H, W, L4b.cout)
+        fuse = self.fuse_bn_bwd_stats
         call('bdn_outc_bwd', self.dt, ptr(dlogits), ptr(ws.z['d4b']), ptr(ws.bn['d4b']), ptr(P['outc.conv.weight']),
-             ptr(dA), ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), B, H, W, L4b.cout, self.n_classes, st)
+             ptr(dA), ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), ptr(ws.stats) if fuse else None,
+             B, H, W, L4b.cout, self.n_classes, st)
+        rows_head = _lib.load().bdn_outc_bwd_rows(self.dt, B, H, W, L4b.cout) if fuse else 0
         ready(['outc.conv.weight', 'outc.conv.bias'])
         # ---- decoder
         dA_ptr, ldA = ptr(dA), L4b.cout
@@ -432,7 +437,7 @@ class BiDateEngine:
             ck = ENC_CH[k - 1]
             cprev = La.cin - ck
             late = self.wgrad_after_dgrad
-            dzb = bn_bwd(Lb, dA_ptr, ldA, B, B)
+            dzb = bn_bwd(Lb, dA_ptr, ldA, B, B, fused_rows=rows_head if j == 4 else 0)
             if not late:
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dAa, rows = dgrad(Lb, dzb, B, B, prev=La)

@@ -162,7 +162,10 @@ int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, cons
                  float* logits, int B, int H, int W, int C, int ncls, void* stream);
 /* dlogits: [B,ncls,H,W] f32 -> dA [B,H,W,C] (wrt relu(bn(z))), dw [ncls][C], db [ncls] (overwritten). */
 int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
-                 void* dA, float* dw, float* db, int B, int H, int W, int C, int ncls, void* stream);
+                 void* dA, float* dw, float* db, float* bs_partial, int B, int H, int W, int C, int ncls, void* stream);
+/* bs_partial: NULL, or f32 [bdn_outc_bwd_rows(dtype,B,H,W,C)][2][C]: BatchNorm-backward partial sums of the layer that
+ * produced z (sum g, sum g*z on the stored dA) -> bdn_bn_bwd_apply(raw_moment = 1, one statistic group). */
+int bdn_outc_bwd_rows(int dtype, int B, int H, int W, int C);
 
 /* ---- TverskyLoss.forward, utils/metrics.py:130-171, for [B,H,W] labels (dims == (0,2)) ----
  * labels: uint8 [B,H,W].  ws: f32 workspace of 3*ncls*W + 8 floats.

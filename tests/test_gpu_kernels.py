@@ -347,9 +347,19 @@ def test_outc_fwd_bwd(prec, shape):
     dA = torch.empty(B, H, W, C, dtype=td, device='cuda')
     dw, db = torch.empty(ncls, C, device='cuda'), torch.empty(ncls, device='cuda')
     dl_d = dev(dl)
+    rows = _lib.load().bdn_outc_bwd_rows(dt, B, H, W, C)
+    part = torch.full((rows, 2, C), float('nan'), device='cuda')
     _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), dA.data_ptr(),
-              dw.data_ptr(), db.data_ptr(), B, H, W, C, ncls, st())
+              dw.data_ptr(), db.data_ptr(), part.data_ptr(), B, H, W, C, ncls, st())
+    dA2 = torch.empty_like(dA)
+    _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), dA2.data_ptr(),
+              dw.data_ptr(), db.data_ptr(), None, B, H, W, C, ncls, st())
     torch.cuda.synchronize()
+    assert torch.equal(dA, dA2)
+    gm = from_nhwc(dA).double() * (bnrelu_ref(prec, z, bn, B) > 0)          # fused BatchNorm-backward partial sums
+    got = part.double().sum(0).cpu()
+    assert_close('sum g', got[0].float(), gm.sum((0, 2, 3)).float(), 2e-5, abs_floor=1e-4)
+    assert_close('sum g*z', got[1].float(), (gm * z.double()).sum((0, 2, 3)).float(), 2e-5, abs_floor=1e-4)
     assert_close('dA', from_nhwc(dA), a.grad.float(), 1e-5 if prec == 'fp32' else 8e-3)
     assert_close('dw', dw.cpu(), wd_.grad.float().reshape(ncls, C), 1e-4)
     assert_close('db', db.cpu(), bd_.grad.float(), 1e-4)
