@@ -199,6 +199,75 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dU, int ldU, T* __re
     }
 }
 
+// Tiled variant: a block owns 8x8 source pixels x 8 channel units.  The 20x20 destination pixels that can reach
+// them ([2y-2, 2y+3] per axis, see above) are staged ONCE in LDS (one coalesced pass over dU, 1.56x halo overhead
+// instead of the ~3x re-reads of the per-pixel gather), then every thread gathers two source pixels from LDS with
+// the same separable weights.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const T* __restrict__ dU, int ldU, T* __restrict__ dsrc,
+                                                                 int h, int w, int H, int W, int C, int tiles_x, int tiles_y,
+                                                                 float sy, float sx) {
+    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, UB = 8, PSTR = UB * 16 + 16;    // 144-byte pixel stride
+    __shared__ __attribute__((aligned(16))) unsigned char sm[R * R * PSTR];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int c0 = blockIdx.y * UB * EPU;
+    const int ys0 = ty * TS, xs0 = tx * TS;
+    const int top = (H - 2 * h) / 2, left = (W - 2 * w) / 2;
+    // ---- stage the destination window (zero outside the upsampled image): all loads in flight before the first LDS store
+    constexpr int NL = (R * R * UB + 255) / 256;
+    uint4 stg[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const int i = tid + j * 256;
+        const int su = i % UB, pix = i / UB, rx = pix % R, ry = pix / R;
+        const int dy = 2 * ys0 - 2 + ry, dx = 2 * xs0 - 2 + rx;
+        stg[j] = make_uint4(0, 0, 0, 0);
+        if (i < R * R * UB && dy >= 0 && dy < 2 * h && dx >= 0 && dx < 2 * w)
+            stg[j] = *reinterpret_cast<const uint4*>(dU + ((size_t)(n * H + dy + top) * W + dx + left) * ldU + c0 + su * EPU);
+    }
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const int i = tid + j * 256;
+        if (i < R * R * UB) *reinterpret_cast<uint4*>(sm + (i / UB) * PSTR + (i % UB) * 16) = stg[j];
+    }
+    __syncthreads();
+    const int uu = tid % UB, sp = tid / UB;                      // 32 pixel lanes x 8 units; two source pixels per thread
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        const int ly = (sp >> 3) + 4 * rep, lx = sp & 7;
+        const int y = ys0 + ly, x = xs0 + lx;
+        if (y >= h || x >= w) continue;
+        float wy[6], wx[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int dy = 2 * y - 2 + k, dx = 2 * x - 2 + k;
+            int a0, a1; float l;
+            wy[k] = 0.f; wx[k] = 0.f;
+            if (dy >= 0 && dy < 2 * h) { up_tap(dy, h, sy, a0, a1, l); wy[k] = (a0 == y ? 1.f - l : 0.f) + (a1 == y ? l : 0.f); }
+            if (dx >= 0 && dx < 2 * w) { up_tap(dx, w, sx, a0, a1, l); wx[k] = (a0 == x ? 1.f - l : 0.f) + (a1 == x ? l : 0.f); }
+        }
+        float o[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) o[i] = 0.f;
+        const unsigned char* base = sm + ((2 * ly) * R + 2 * lx) * PSTR + uu * 16;
+#pragma unroll
+        for (int ky = 0; ky < 6; ky++) {
+            if (wy[ky] == 0.f) continue;
+#pragma unroll
+            for (int kx = 0; kx < 6; kx++) {
+                if (wx[kx] == 0.f) continue;
+                float f[EPU];
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(base + (ky * R + kx) * PSTR), f);
+                const float wgt = wy[ky] * wx[kx];
+#pragma unroll
+                for (int i = 0; i < EPU; i++) o[i] += wgt * f[i];
+            }
+        }
+        *reinterpret_cast<uint4*>(dsrc + ((size_t)(n * h + y) * w + x) * C + c0 + uu * EPU) = Unit<T>::pack(o);
+    }
+}
+
 extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
                                   int B, int h, int w, int H, int W, int C, void* stream) {
     if (!dU || !dsrc) BDN_FAIL(BDN_E_ARG, "upsample2x_bwd: null pointer");
@@ -206,6 +275,15 @@ extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc
     hipStream_t st = (hipStream_t)stream;
     const int npix = B * h * w;
     const float sy = up_scale(h), sx = up_scale(w);
+    const int epu = dtype == BDN_BF16 ? 8 : 4;
+    if (h >= 8 && w >= 8 && C % (8 * epu) == 0 && (dtype == BDN_BF16 || dtype == BDN_F32)) {
+        const int tx = (w + 7) / 8, ty = (h + 7) / 8;
+        const dim3 grid(tx * ty * B, C / (8 * epu));
+        if (dtype == BDN_BF16) hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel<bf16s>, grid, dim3(256), 0, st, (const bf16s*)dU, ldU, (bf16s*)dsrc, h, w, H, W, C, tx, ty, sy, sx);
+        else hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)dU, ldU, (float*)dsrc, h, w, H, W, C, tx, ty, sy, sx);
+        BDN_CHECK_LAUNCH("upsample2x_bwd_tiled");
+        return BDN_OK;
+    }
     if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS;
         hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)dU, ldU, (bf16s*)dsrc, npix, h, w, H, W, C, sy, sx); }
     else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS;

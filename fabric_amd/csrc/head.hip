@@ -7,17 +7,24 @@ static inline unsigned grid_for(size_t n, int block = 256) { return (unsigned)((
 
 // ============================================================ pack_input
 // reference boundary: BiDateNet.forward(x_d1, x_d2), models/bidate_model.py:22 (NCHW f32)
+// One thread per (pixel, 16-byte output unit): the band planes are read coalesced along x, every store is 16 bytes
+// (the first version wrote Cpad scalars per thread: 100 us for 176 MB).
 template <typename T>
 __global__ void pack_input_kernel(const float* __restrict__ x1, const float* __restrict__ x2, T* __restrict__ out,
                                   int B, int C, int H, int W, int Cpad) {
-    const size_t npix = (size_t)2 * B * H * W;
+    constexpr int EPU = ET<T>::EPU;
+    const int upp = Cpad / EPU;
+    const size_t hw = (size_t)H * W, total = (size_t)2 * B * hw * upp;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
-    const size_t hw = (size_t)H * W;
-    const int n = i / hw; const size_t p = i % hw;
+    if (i >= total) return;
+    // the unit index is the slow coordinate inside an image so that a wave reads 64 consecutive pixels of one plane set
+    const size_t p = i % hw; size_t t = i / hw;
+    const int u = t % upp; const int n = t / upp;
     const float* src = (n < B ? x1 + (size_t)n * C * hw : x2 + (size_t)(n - B) * C * hw) + p;
-    T* dst = out + i * Cpad;
-    for (int c = 0; c < Cpad; c++) dst[c] = from_f<T>(c < C ? src[(size_t)c * hw] : 0.f);
+    float f[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; e++) { const int c = u * EPU + e; f[e] = c < C ? src[(size_t)c * hw] : 0.f; }
+    *reinterpret_cast<uint4*>(out + ((size_t)n * hw + p) * Cpad + u * EPU) = Unit<T>::pack(f);
 }
 
 extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,
@@ -26,8 +33,8 @@ extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, v
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || Cpad % 16) BDN_FAIL(BDN_E_SHAPE, "pack_input: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)2 * B * H * W;
-    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16s>, dim3(grid_for(npix)), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad);
-    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, st, x_d1, x_d2, (float*)out, B, C, H, W, Cpad);
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16s>, dim3(grid_for(npix * (Cpad / 8))), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad);
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(npix * (Cpad / 4))), dim3(256), 0, st, x_d1, x_d2, (float*)out, B, C, H, W, Cpad);
     else BDN_FAIL(BDN_E_ARG, "pack_input: bad dtype");
     BDN_CHECK_LAUNCH("pack_input");
     return BDN_OK;

@@ -246,7 +246,8 @@ def test_fuse_product(prec):
     assert_close('product', from_nhwc(out), ref, 1e-6 if prec == 'fp32' else 8e-3)
 
 
-UP_CASES = [(2, 8, 8, 16, 16, 64), (2, 5, 5, 11, 11, 64), (1, 22, 22, 45, 45, 32), (2, 1, 1, 2, 3, 16), (1, 3, 7, 6, 14, 64)]
+UP_CASES = [(2, 8, 8, 16, 16, 64), (2, 5, 5, 11, 11, 64), (1, 22, 22, 45, 45, 32), (2, 1, 1, 2, 3, 16), (1, 3, 7, 6, 14, 64),
+            (2, 22, 19, 45, 39, 128), (1, 16, 32, 32, 64, 256), (1, 9, 8, 18, 17, 64)]
 
 
 @pytest.mark.parametrize('prec', PRECS)
