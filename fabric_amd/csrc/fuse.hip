@@ -199,7 +199,8 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dU, int ldU, T* __re
     }
 }
 
-// Tiled variant: a block owns 8x8 source pixels x 8 channel units.  The 20x20 destination pixels that can reach
+// Tiled variant: a block owns 8x8 source pixels x 4 channel units (32 KB of LDS: small enough to share a CU with
+// the weight-gradient GEMM that runs beside the chain on the second stream).  The 20x20 destination pixels that can reach
 // them ([2y-2, 2y+3] per axis, see above) are staged ONCE in LDS (one coalesced pass over dU, 1.56x halo overhead
 // instead of the ~3x re-reads of the per-pixel gather), then every thread gathers two source pixels from LDS with
 // the same separable weights.
@@ -207,7 +208,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const T* __restrict__ dU, int ldU, T* __restrict__ dsrc,
                                                                  int h, int w, int H, int W, int C, int tiles_x, int tiles_y,
                                                                  float sy, float sx) {
-    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, UB = 8, PSTR = UB * 16 + 16;    // 144-byte pixel stride
+    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, UB = 4, PSTR = UB * 16 + 16;    // 80-byte pixel stride
     __shared__ __attribute__((aligned(16))) unsigned char sm[R * R * PSTR];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -232,12 +233,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const T* __re
         if (i < R * R * UB) *reinterpret_cast<uint4*>(sm + (i / UB) * PSTR + (i % UB) * 16) = stg[j];
     }
     __syncthreads();
-    const int uu = tid % UB, sp = tid / UB;                      // 32 pixel lanes x 8 units; two source pixels per thread
-#pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
-        const int ly = (sp >> 3) + 4 * rep, lx = sp & 7;
+    const int uu = tid % UB, sp = tid / UB;                      // 64 source pixels x 4 units
+    {
+        const int ly = sp >> 3, lx = sp & 7;
         const int y = ys0 + ly, x = xs0 + lx;
-        if (y >= h || x >= w) continue;
+        if (y >= h || x >= w) return;
         float wy[6], wx[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -276,9 +276,9 @@ extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc
     const int npix = B * h * w;
     const float sy = up_scale(h), sx = up_scale(w);
     const int epu = dtype == BDN_BF16 ? 8 : 4;
-    if (h >= 8 && w >= 8 && C % (8 * epu) == 0 && (dtype == BDN_BF16 || dtype == BDN_F32)) {
+    if (h >= 8 && w >= 8 && C % (4 * epu) == 0 && (dtype == BDN_BF16 || dtype == BDN_F32)) {
         const int tx = (w + 7) / 8, ty = (h + 7) / 8;
-        const dim3 grid(tx * ty * B, C / (8 * epu));
+        const dim3 grid(tx * ty * B, C / (4 * epu));
         if (dtype == BDN_BF16) hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel<bf16s>, grid, dim3(256), 0, st, (const bf16s*)dU, ldU, (bf16s*)dsrc, h, w, H, W, C, tx, ty, sy, sx);
         else hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)dU, ldU, (float*)dsrc, h, w, H, W, C, tx, ty, sy, sx);
         BDN_CHECK_LAUNCH("upsample2x_bwd_tiled");

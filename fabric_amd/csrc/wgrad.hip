@@ -212,7 +212,10 @@ struct Wg2 {
 };
 
 template <bool USE_BN>
-__global__ __launch_bounds__(256, 1) void wgrad2_kernel(WgradArgs a) {
+#ifndef WG2_OCC
+#define WG2_OCC 1
+#endif
+__global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
     constexpr int PW = Wg2::PW, STR = Wg2::STR, BUF = Wg2::BUF, PATCH_BYTES = Wg2::PATCH_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;

@@ -183,8 +183,8 @@ class BiDateEngine:
             t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
         else:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
-        one = ',one' if th == 16 and (c0 + c1) * self.esize == ckb else ''      # single-chunk variant (3 blocks per CU)
-        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn}{one}>'
+        one = 'true' if th == 16 and (c0 + c1) * self.esize == ckb else 'false'    # single-chunk variant (3 blocks per CU)
+        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn},{one}>'
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
         name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
