@@ -32,6 +32,7 @@ SIGNATURES = {
     'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_product_pool': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

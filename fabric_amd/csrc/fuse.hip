@@ -96,6 +96,65 @@ extern "C" int bdn_fuse_product(int dtype, const void* z, const float* bn, void*
     return BDN_OK;
 }
 
+// ============================================================ product fusion + MaxPool2d(2) in one pass over z
+// reference models/bidate_model.py:35-38 + models/unet_parts.py:40: the skip f = relu(a_d2 * a_d1) of an encoder level
+// and the pooled input of the next level (both dates) both start from a = relu(bn(z)) of the same tensor; one
+// iteration = one 2x2 window x EPU channels x both dates, so z is read from HBM once instead of twice.
+template <typename T>
+__global__ void product_pool_kernel(const T* __restrict__ z, const float* __restrict__ bn, T* __restrict__ f, T* __restrict__ pool,
+                                    int B, int H, int W, int C, int ncell) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+    float sc0[EPU], sh0[EPU], sc1[EPU], sh1[EPU];
+    load_consts<T>(bn_row(bn, 0, 2, C) + c, sc0); load_consts<T>(bn_row(bn, 0, 3, C) + c, sh0);
+    load_consts<T>(bn_row(bn, 1, 2, C) + c, sc1); load_consts<T>(bn_row(bn, 1, 3, C) + c, sh1);
+    constexpr int IT = 4;
+    const int q_end = min(ncell, (int)(blockIdx.x + 1) * rows * IT);
+    for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
+        const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
+        float m0[EPU], m1[EPU];
+#pragma unroll
+        for (int i = 0; i < EPU; i++) { m0[i] = 0.f; m1[i] = 0.f; }     // activations are >= 0
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            if (y < H && x < W) {
+                const size_t p0 = (size_t)(b * H + y) * W + x, p1 = (size_t)((B + b) * H + y) * W + x;
+                float a0[EPU], a1[EPU];
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p0 * C + c), a0);
+                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p1 * C + c), a1);
+#pragma unroll
+                for (int i = 0; i < EPU; i++) {
+                    a0[i] = act1<T>(a0[i], sc0[i], sh0[i]); a1[i] = act1<T>(a1[i], sc1[i], sh1[i]);
+                    m0[i] = fmaxf(m0[i], a0[i]); m1[i] = fmaxf(m1[i], a1[i]);
+                    a0[i] *= a1[i];                                         // >= 0: relu is a no-op
+                }
+                *reinterpret_cast<uint4*>(f + p0 * C + c) = Unit<T>::pack(a0);
+            }
+        }
+        if (yc < Ho && xc < Wo) {                                           // floor-mode pooling drops a trailing odd row / column
+            *reinterpret_cast<uint4*>(pool + ((size_t)(b * Ho + yc) * Wo + xc) * C + c) = Unit<T>::pack(m0);
+            *reinterpret_cast<uint4*>(pool + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c) = Unit<T>::pack(m1);
+        }
+    }
+}
+
+extern "C" int bdn_product_pool(int dtype, const void* z, const float* bn, void* f, void* pool,
+                                int B, int H, int W, int C, void* stream) {
+    if (!z || !bn || !f || !pool) BDN_FAIL(BDN_E_ARG, "product_pool: null pointer");
+    if (C % 16 || C > 1024 || 1024 % C || H < 2 || W < 2) BDN_FAIL(BDN_E_SHAPE, "product_pool: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
+        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
+        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell); }
+    else BDN_FAIL(BDN_E_ARG, "product_pool: bad dtype");
+    BDN_CHECK_LAUNCH("product_pool");
+    return BDN_OK;
+}
+
 // ============================================================ bilinear x2 (align_corners=True) + F.pad
 // source index / weight of destination index d (ATen area_pixel_compute_source_index, align_corners)
 __device__ __forceinline__ void up_tap(int d, int n_in, float scale, int& i0, int& i1, float& lam) {

@@ -311,16 +311,13 @@ class BiDateEngine:
         for k in range(1, 6):
             hk, wk = ws.dims[k - 1]
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
-            if k == 1:
-                src = ws.x0
-            else:
-                hp, wp = ws.dims[k - 2]
-                call('bdn_bnrelu_pool', self.dt, ptr(ws.z[f'e{k - 1}b']), ptr(ws.bn[f'e{k - 1}b']), B,
-                     ptr(ws.pool[k]), 2 * B, hp, wp, ENC_CH[k - 2], st)
-                src = ws.pool[k]
+            src = ws.x0 if k == 1 else ws.pool[k]           # pool[k] was written together with the skip of level k-1
             za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st, rb)
-            call('bdn_fuse_product', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], st)
+            if k < 5:                                       # skip f_k and the pooled input of level k+1 in one pass over z
+                call('bdn_product_pool', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), ptr(ws.pool[k + 1]), B, hk, wk, ENC_CH[k - 1], st)
+            else:
+                call('bdn_fuse_product', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], st)
         # ---- decoder on the fused skips
         prev, prev_bn, prev_mode, cprev = ws.f[5], None, IN_PLAIN, ENC_CH[4]
         for j in range(1, 5):

@@ -135,6 +135,10 @@ int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_grou
  * z: [2B,H,W,C] raw conv outputs of both dates, bn: [2][4][C]; f: [B,H,W,C]. */
 int bdn_fuse_product(int dtype, const void* z, const float* bn, void* f,
                      int B, int H, int W, int C, void* stream);
+/* Both of the above in one pass over z (every encoder level but the last needs the skip AND the pooled maps):
+ * f [B,H,W,C] = relu(a_d2*a_d1), pool [2B,H/2,W/2,C] = MaxPool2d(2)(a), a = relu(bn(z)), z [2B,H,W,C] date 1 first. */
+int bdn_product_pool(int dtype, const void* z, const float* bn, void* f, void* pool,
+                     int B, int H, int W, int C, void* stream);
 
 /* ---- nn.Upsample(scale_factor=2, bilinear, align_corners=True) + F.pad: models/unet_parts.py:56-58,68-72 ----
  * src: [B,h,w,C] (plain, or raw z with bn when in_mode = BDN_IN_BNRELU); out: [B,H,W,C] with the

@@ -500,3 +500,20 @@ def test_dgrad_with_fused_bn_bwd_stats(prec, case):
     assert_close('dbeta', db.cpu(), db_r.cpu(), 2e-5)
     assert_close('dgamma', dg.cpu(), dg_r.cpu(), 2e-5, abs_floor=2e-4)
     assert_close('dz', dz.float().cpu(), dz_r.float().cpu(), 8e-3 if prec == 'bf16' else 2e-5)
+
+
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (1, 45, 22, 64), (2, 11, 11, 128), (1, 2, 3, 256)])
+def test_product_pool_equals_separate_kernels(prec, shape):
+    """bdn_product_pool == bdn_fuse_product + bdn_bnrelu_pool, bit for bit (odd sizes: floor-mode pooling)."""
+    B, H, W, C = shape
+    dt, td = DT[prec]
+    z_d = to_nhwc(prec, rnd(prec, _rand((2 * B, C, H, W), 71)))
+    bn_d = dev(bn_table(2, C, 72))
+    f1 = torch.empty(B, H, W, C, dtype=td, device='cuda'); f2 = torch.full_like(f1, 3.0)
+    p1 = torch.empty(2 * B, H // 2, W // 2, C, dtype=td, device='cuda'); p2 = torch.full_like(p1, 3.0)
+    _lib.call('bdn_fuse_product', dt, z_d.data_ptr(), bn_d.data_ptr(), f1.data_ptr(), B, H, W, C, st())
+    _lib.call('bdn_bnrelu_pool', dt, z_d.data_ptr(), bn_d.data_ptr(), B, p1.data_ptr(), 2 * B, H, W, C, st())
+    _lib.call('bdn_product_pool', dt, z_d.data_ptr(), bn_d.data_ptr(), f2.data_ptr(), p2.data_ptr(), B, H, W, C, st())
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f2) and torch.equal(p1, p2)
