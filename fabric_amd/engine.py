@@ -162,6 +162,8 @@ class BiDateEngine:
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
         self._diag_skip_wgrad = False
         self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
+        self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
+        self._prof_seen = 0
         self.prof_filter = None    # only time launches of this kernel instantiation (an event pair is a ~150 us pipeline bubble)
         self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
@@ -191,6 +193,11 @@ class BiDateEngine:
         if self.prof is None or (self.prof_filter is not None and name != self.prof_filter):
             call(fn, *args)
             return
+        if self.prof_pick is not None:              # sparse sampling: bracket only the prof_pick-th matching launch of this step
+            self._prof_seen += 1
+            if self._prof_seen - 1 != self.prof_pick:
+                call(fn, *args)
+                return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call(fn, *args)
@@ -266,6 +273,7 @@ class BiDateEngine:
     def forward(self, x_d1, x_d2, P, training=True):
         """x_d1, x_d2: [B,C,H,W] float32 CUDA tensors (reference layout).  P: state-dict-keyed tensors.
         Returns (logits [B,n_classes,H,W] float32, workspace)."""
+        self._prof_seen = 0
         if not (x_d1.is_cuda and x_d2.is_cuda):
             raise RuntimeError('fabric_amd: BiDateNet runs only on a ROCm device (MI355X); '
                                'inputs must be CUDA/HIP tensors -- there is no CPU path')
