@@ -48,6 +48,7 @@ SIGNATURES = {
     'bdn_overlap_loss': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_focal_workspace_bytes': (_sz, []),
     'bdn_focal': (_i, [_vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_ingest_band': (_i, [_i, _vp, _i, _i, _f, _f, _vp, _i, _i, _vp]),
     'bdn_gather_tiles': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_argmax': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_argmax_stitch': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

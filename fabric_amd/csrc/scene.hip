@@ -56,6 +56,43 @@ extern "C" int bdn_gather_tiles(int dtype, const float* scene_d1, const float* s
     return BDN_OK;
 }
 
+// ============================================================ ingest: per-band normalisation + resize to the label grid
+// reference utils/dataloaders.py:86-111 (city_loader): band = (band.astype(float32) - mean) / std; band = cv2.resize(band,
+// (W, H)) (default INTER_LINEAR).  Sentinel-2 bands come at 10 / 20 / 60 m, the label raster at 10 m, so most bands
+// are upsampled 2x or 6x into their plane of the [C][H][W] scene that the tile gather reads.
+// cv2's float INTER_LINEAR (OpenCV imgproc/resize.cpp): fx = (dx + 0.5) * (src_w / dst_w) - 0.5, sx = floor(fx),
+// fx -= sx, clamped to [0, src_w - 1] with weight (1, 0) at either border; rows alike; horizontal pass first.
+template <typename S>
+__global__ void ingest_band_kernel(const S* __restrict__ src, int hs, int ws, float mean, float stdv,
+                                   float* __restrict__ dst, int H, int W, double scale_y, double scale_x) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float fy = (float)((y + 0.5) * scale_y - 0.5), fx = (float)((x + 0.5) * scale_x - 0.5);
+    int sy = (int)floorf(fy), sx = (int)floorf(fx);
+    fy -= (float)sy; fx -= (float)sx;
+    if (sy < 0) { sy = 0; fy = 0.f; }
+    if (sy >= hs - 1) { sy = hs - 1; fy = 0.f; }
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= ws - 1) { sx = ws - 1; fx = 0.f; }
+    const int sy1 = min(sy + 1, hs - 1), sx1 = min(sx + 1, ws - 1);
+    const float a00 = ((float)src[(size_t)sy * ws + sx] - mean) / stdv, a01 = ((float)src[(size_t)sy * ws + sx1] - mean) / stdv;
+    const float a10 = ((float)src[(size_t)sy1 * ws + sx] - mean) / stdv, a11 = ((float)src[(size_t)sy1 * ws + sx1] - mean) / stdv;
+    const float r0 = a00 * (1.f - fx) + a01 * fx, r1 = a10 * (1.f - fx) + a11 * fx;      // horizontal pass, then vertical
+    dst[(size_t)y * W + x] = r0 * (1.f - fy) + r1 * fy;
+}
+
+extern "C" int bdn_ingest_band(int src_is_f32, const void* src, int hs, int ws, float mean, float stdv,
+                               float* dst, int H, int W, void* stream) {
+    if (!src || !dst) BDN_FAIL(BDN_E_ARG, "ingest_band: null pointer");
+    if (hs <= 0 || ws <= 0 || H <= 0 || W <= 0 || !(stdv != 0.f)) BDN_FAIL(BDN_E_SHAPE, "ingest_band: bad shape or zero std");
+    const dim3 grid((W + 255) / 256, H);
+    const double sy = (double)hs / H, sx = (double)ws / W;
+    if (src_is_f32) hipLaunchKernelGGL(ingest_band_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, hs, ws, mean, stdv, dst, H, W, sy, sx);
+    else hipLaunchKernelGGL(ingest_band_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, hs, ws, mean, stdv, dst, H, W, sy, sx);
+    BDN_CHECK_LAUNCH("ingest_band");
+    return BDN_OK;
+}
+
 // ============================================================ argmax (+ stitch)
 // reference: `_, cd_preds = torch.max(preds, 1)` train.py:199 (first maximum wins ties), then
 // utils/inference.py:187-236 (_get_bands): main tiles, then last-column tiles, then last-row tiles, then the

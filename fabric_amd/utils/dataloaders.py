@@ -1,10 +1,10 @@
 """OSCD patch-pair dataset API: drop-in for the reference's utils/dataloaders.py:148-198 (the part of
 that file that sits on the hot path: cropping / augmenting patch pairs out of pre-loaded city stacks).
 
-Host-side numpy, like the reference.  GeoTIFF ingest (city_loader / full_onera_loader, reference
-utils/dataloaders.py:86-145) needs rasterio + cv2, which this image does not have: those entry points
-keep the reference's names and signatures and raise ImportError lazily; `synthetic_onera` builds a
-dataset of the same schema for benchmarks and tests.
+Host-side numpy, like the reference.  The ingest half of that file (city_loader / full_onera_loader /
+label_loader / get_train_val_metadata, reference utils/dataloaders.py:51-145) is fabric_amd.utils.ingest and is
+re-exported from here under the reference's names; `synthetic_onera` builds a dataset of the same schema
+for benchmarks and tests.
 """
 import random
 
@@ -88,9 +88,11 @@ def synthetic_onera(n_cities=4, bands=13, size=(300, 260), seed=0, change_fracti
     return out
 
 
-def _needs_geo(*_a, **_k):
-    raise ImportError('fabric_amd: GeoTIFF ingest (reference utils/dataloaders.py:86-145) needs rasterio and cv2, '
-                      'which are not installed here; use synthetic_onera() or pre-load the city stacks yourself')
-
-
-city_loader = full_onera_loader = label_loader = get_train_val_metadata = _needs_geo
+def __getattr__(name):
+    """city_loader / full_onera_loader / label_loader / get_train_val_metadata (reference utils/dataloaders.py:51-145) live in
+    fabric_amd.utils.ingest (own TIFF / PNG decoding + device-side normalise-and-resize); resolved lazily because that
+    module needs the HIP library."""
+    if name in ('city_loader', 'full_onera_loader', 'label_loader', 'get_train_val_metadata'):
+        from . import ingest
+        return getattr(ingest, name)
+    raise AttributeError(name)

@@ -13,8 +13,8 @@ Two ways in:
 Tiles are independent: several GPUs take disjoint slices of the tile list (``shard=(rank, world)``); the only
 exchange is the optional final merge of the uint8 masks.
 
-GeoTIFF reading (``generate_patches``, utils/inference.py:20-70) and comet logging (``log_full_image``) need
-rasterio / cv2 / comet_ml, which are outside this path.
+``generate_patches`` (utils/inference.py:20-70) reads the band files through fabric_amd.utils.ingest; comet logging
+(``log_full_image``) is outside this path.
 """
 from os import path
 
@@ -70,13 +70,23 @@ def full_image_mask(out, hs, ws, lc, lr, h, w, patch_size):
     return _get_bands(np.vstack(out), hs, ws, lc, lr, h, w, patch_size=patch_size)
 
 
-def _needs_geo(*_a, **_k):
-    raise ImportError('fabric_amd: generate_patches / log_full_image (reference utils/inference.py:20-131) need '
-                      'rasterio, cv2 and comet_ml, which are not installed here; load the two [13,H,W] date stacks '
-                      'yourself and call predict_scene()')
+def generate_patches(opt, validation_city):
+    """utils/inference.py:20-70: both dates of a city as patch stacks [n,C,p,p] + the reconstruction metadata.  Band files
+    are decoded by fabric_amd.utils.ingest (own TIFF reader, device-side normalise + resize) instead of rasterio / cv2."""
+    import glob
+    from . import ingest
+    city_dir = path.join(opt.dataset_dir, 'images', validation_city)      # (get_path would strip the root of an absolute dir)
+    d1_bands = sorted(glob.glob(path.join(city_dir, 'imgs_1', '*')))
+    template = ingest.read_tiff(d1_bands[2])                   # band 2 gives the 10 m grid (utils/inference.py:47)
+    stack = ingest.city_loader([city_dir, template.shape[1], template.shape[0], opt])
+    p1, hs, ws, lc, lr, h, w = _get_patches(stack[0].transpose(1, 2, 0), patch_dim=opt.patch_size)
+    p2 = _get_patches(stack[1].transpose(1, 2, 0), patch_dim=opt.patch_size)[0]
+    return p1.transpose(0, 3, 1, 2), p2.transpose(0, 3, 1, 2), hs, ws, lc, lr, h, w
 
 
-generate_patches = log_full_image = _needs_geo
+def log_full_image(*_a, **_k):
+    raise ImportError('fabric_amd: log_full_image (reference utils/inference.py:72-131) uploads figures through comet_ml and '
+                      'cv2, which are outside this path; full_image_mask() returns the stitched array')
 
 
 def _eval_params(model):

@@ -198,6 +198,14 @@ int bdn_focal(const float* logits, const uint8_t* labels, float gamma, const flo
               void* ws, float* loss, int32_t* counts, float* dlogits,
               int B, int ncls, int H, int W, void* stream);
 
+/* ---- OSCD ingest: utils/dataloaders.py:86-111 city_loader, per band ----
+ * dst [H][W] f32 (one plane of a [C][H][W] scene) = cv2.resize((src - mean) / std, (W, H)) with cv2's default float
+ * INTER_LINEAR sampling (half-pixel centres, border weights (1,0)).  src: [hs][ws] uint16 (src_is_f32 = 0) or f32, on
+ * the device.  cv2 is not installed in the build image, so this row's parity is pinned only against the written-out
+ * algorithm (oracle/ingest_oracle.py), not against cv2 itself. */
+int bdn_ingest_band(int src_is_f32, const void* src, int hs, int ws, float mean, float stdv,
+                    float* dst, int H, int W, void* stream);
+
 /* ---- full-scene sliding-window inference: train.py:182-205, utils/inference.py:134-236 ----
  * The scene stays in HBM as band planes scene_d*: [C][H][W] f32.  origins: device int32 [n_tiles][2] = (y0, x0)
  * in the reference's tile order (utils/inference.py:160-184: hs*ws main tiles, lc last-column tiles, lr last-row

@@ -159,4 +159,4 @@ def test_scene_errors():
     with pytest.raises(ValueError, match='smaller'):
         inf.predict_scene(model.eval(), d, d, patch_size=128)
     with pytest.raises(ImportError):
-        inf.generate_patches(None, 'city')
+        inf.log_full_image(None)
