@@ -53,7 +53,7 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool BF = true>
 struct ConvCfg {
     using TL = Tile<TH, TW, TI>;
     static constexpr int ES = sizeof(T);
@@ -69,8 +69,13 @@ struct ConvCfg {
     static constexpr int ROWP = TL::PW * PSTR + RPAD;
     static constexpr int MI = BM / (WM * 32), NJ = BN / (WN * 32);
     static constexpr int KG = CKB / 32;                // k-groups (32 bytes of channels) per chunk
-    static constexpr int PATCH_BYTES = TI * TL::PH * ROWP;
-    static constexpr int PBUF = (2 * PATCH_BYTES <= 56 * 1024) ? 2 : 1;   // double-buffer when two blocks still fit a CU
+    static constexpr int NPU0 = (TL::NPIX * UPP + 255) / 256;
+    // rows backed by LDS: the patch itself, rounded up so that EVERY thread's unit slots (NPU0 * 256 of them, the
+    // tail beyond the patch is padding) have an address -- staging then needs no per-unit bounds branch
+    static constexpr int ROWS_ALLOC = ((NPU0 * 256 / UPP) + TL::PW - 1) / TL::PW;
+    static constexpr int PATCH_ROWS = (BF && ROWS_ALLOC > TI * TL::PH) ? ROWS_ALLOC : TI * TL::PH;   // BF: branch-free staging
+    static constexpr int PATCH_BYTES = PATCH_ROWS * ROWP;
+    static constexpr int PBUF = (2 * PATCH_BYTES <= 64 * 1024) ? 2 : 1;   // double-buffer when two blocks still fit a CU
     static constexpr int OSTR = BN * ES + 16;
     static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
     static constexpr int MAIN_BYTES = PBUF * PATCH_BYTES;
@@ -92,7 +97,7 @@ template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, b
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 __global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
-    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
+    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
     constexpr int EPU = CF::EPU, UPP = CF::UPP, NPU = CF::NPU, CK = CF::CK, PBUF = CF::PBUF;
@@ -143,14 +148,16 @@ __global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void c
         }
     }
     const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
+    constexpr bool BRANCHFREE = !ONE;
     uint4 preg[NPU];
 #define LOAD_PATCH(c0_)                                                                                  \
     {                                                                                                   \
         const T* src_; int cs_, Cs_;                                                                    \
         if ((c0_) < a.C0) { src_ = reinterpret_cast<const T*>(a.in0); Cs_ = a.C0; cs_ = (c0_); }        \
         else { src_ = reinterpret_cast<const T*>(a.in1); Cs_ = a.C1; cs_ = (c0_) - a.C0; }              \
-        _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
-            if (p_pix[i] >= 0) preg[i] = *reinterpret_cast<const uint4*>(src_ + (size_t)p_pix[i] * Cs_ + cs_ + p_sub); \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++)       /* padding units read pixel 0 and are zeroed at the store */ \
+            if (BRANCHFREE || p_pix[i] >= 0)                                                            \
+                preg[i] = *reinterpret_cast<const uint4*>(src_ + (size_t)(p_pix[i] >= 0 ? p_pix[i] : 0) * Cs_ + cs_ + p_sub); \
     }
 #define STORE_PATCH(c0_, buf_)                                                                           \
     {                                                                                                   \
@@ -164,8 +171,13 @@ __global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void c
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
             const int u_ = tid + i * 256;                  /* LDS offset recomputed: cheaper than 11 live registers */ \
-            if (u_ < TL::NPIX * UPP) {                                                                  \
-                const int pix_ = u_ / UPP, xx_ = pix_ % TL::PW, t_ = pix_ / TL::PW;                      \
+            const int pix_ = u_ / UPP, xx_ = pix_ % TL::PW, t_ = pix_ / TL::PW;                          \
+            if (BRANCHFREE) {                              /* multi-chunk kernels: the staging is scheduled into the MFMAs */ \
+                uint4 v_ = bn_ ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];                           \
+                const bool ok_ = p_pix[i] >= 0;                                                         \
+                v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+                *reinterpret_cast<uint4*>(pb_ + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = v_;          \
+            } else if (u_ < TL::NPIX * UPP) {              /* single-chunk kernels stage once, in the prologue */ \
                 uint4 v_ = make_uint4(0, 0, 0, 0);                                                      \
                 if (p_pix[i] >= 0) v_ = bn_ ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];              \
                 *reinterpret_cast<uint4*>(pb_ + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = v_;          \
@@ -178,9 +190,13 @@ __global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void c
     // kept in scratch).  Record index: ((cout/32 * 9 + tap) * Cin/KCH + c/KCH); see wfrag_index in common.hpp.
     constexpr int KCH = 32 / CF::ES;                     // channels per k-group
     const int kgroups = Cin / KCH;                       // records per (cout block, tap)
+    // wave-uniform base (scalar registers) + the lane's 16-byte slot as a 32-bit offset: the loads take the
+    // SGPR-base addressing form and need no per-load 64-bit vector address arithmetic
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);
     const unsigned char* wb0 = reinterpret_cast<const unsigned char*>(a.w)
-        + ((size_t)((col0 >> 5) + wn * NJ) * 9 * kgroups) * 1024 + lane * 16;
+        + ((size_t)((col0 >> 5) + wn_u * NJ) * 9 * kgroups) * 1024;
     const unsigned char* wb1 = wb0 + (size_t)9 * kgroups * 1024;     // second cout block of this wave (NJ == 2)
+    const unsigned lane16 = lane * 16;
     // Ring of three register sets r0/r1/r2, one per STEP (= half a tap when a chunk has four k-groups, a whole
     // tap otherwise).  Step s computes from ring[s % 3] while the loads of step s+2 land in ring[(s+2) % 3];
     // a chunk has 9 or 18 steps (multiples of 3), so every index is a compile-time constant, nothing is
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void c
     static_assert(KPS <= 2 && NST % 3 == 0, "ring layout");
     uint4 r0_00, r0_01, r0_10, r0_11, r1_00, r1_01, r1_10, r1_11, r2_00, r2_01, r2_10, r2_11;   // [nj][kps]
     r0_00 = r0_01 = r0_10 = r0_11 = r1_00 = r1_01 = r1_10 = r1_11 = r2_00 = r2_01 = r2_10 = r2_11 = make_uint4(0, 0, 0, 0);
-#define LDB(p_, k_) (*reinterpret_cast<const uint4*>((p_) + (k_) * 1024))
+#define LDB(p_, k_) (*reinterpret_cast<const uint4*>((p_) + (k_) * 1024 + lane16))
     // load the fragments of step st_ (tap st_/SPT, k-groups (st_%SPT)*KPS ...) of the chunk whose record offset is rec_
 #define LOAD_R(R, st_, rec_)                                                                             \
     {                                                                                                   \
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void c
 
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
-    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN>;
+    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE>;
     auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE>;
     static bool attr_set = false;
     if (!attr_set) {
