@@ -21,7 +21,7 @@ dA = torch.empty_like(z); dw = torch.empty(2, 64, device='cuda'); db = torch.emp
 gb = lambda *ts: sum(t.numel() * t.element_size() for t in ts) / 1e9
 t = timeit(lambda: _lib.call('bdn_outc_fwd', dt, z.data_ptr(), bn.data_ptr(), w.data_ptr(), b.data_ptr(), logits.data_ptr(), B, S, S, 64, 2, st))
 print(f'outc_fwd {t:7.1f} us  {gb(z, logits) / t * 1e6:6.0f} GB/s')
-t = timeit(lambda: _lib.call('bdn_outc_bwd', dt, dl.data_ptr(), z.data_ptr(), bn.data_ptr(), w.data_ptr(), dA.data_ptr(), dw.data_ptr(), db.data_ptr(), B, S, S, 64, 2, st))
+t = timeit(lambda: _lib.call('bdn_outc_bwd', dt, dl.data_ptr(), z.data_ptr(), bn.data_ptr(), w.data_ptr(), dA.data_ptr(), dw.data_ptr(), db.data_ptr(), None, B, S, S, 64, 2, st))
 print(f'outc_bwd {t:7.1f} us  {gb(z, dl, dA) / t * 1e6:6.0f} GB/s')
 lbl = (torch.rand(B, S, S, device='cuda') < 0.1).to(torch.uint8)
 ws = torch.empty(3 * 2 * S + 8, device='cuda'); loss = torch.empty(1, device='cuda'); cnt = torch.empty(4, dtype=torch.int32, device='cuda')
@@ -32,7 +32,7 @@ t = timeit(lambda: _lib.call('bdn_pack_input', dt, x1.data_ptr(), x1.data_ptr(),
 print(f'pack_in  {t:7.1f} us  {gb(x1, x1, x0) / t * 1e6:6.0f} GB/s')
 # encoder level-1 sized kernels
 z2 = rnd(2 * B, S, S, 64); dF = rnd(B, S, S, 128); dP = rnd(2 * B, S // 2, S // 2, 64); dA2 = torch.empty_like(z2)
-t = timeit(lambda: _lib.call('bdn_enc_skip_bwd', dt, dF.data_ptr(), 128, z2.data_ptr(), bn.data_ptr(), dP.data_ptr(), dA2.data_ptr(), B, S, S, 64, st))
+t = timeit(lambda: _lib.call('bdn_enc_skip_bwd', dt, dF.data_ptr(), 128, z2.data_ptr(), bn.data_ptr(), dP.data_ptr(), dA2.data_ptr(), None, B, S, S, 64, st))
 print(f'enc_skip_bwd L1 {t:7.1f} us  {(gb(z2, dP, dA2) + gb(dF) / 2) / t * 1e6:6.0f} GB/s')
 f = torch.empty(B, S, S, 64, device='cuda', dtype=td)
 t = timeit(lambda: _lib.call('bdn_fuse_product', dt, z2.data_ptr(), bn.data_ptr(), f.data_ptr(), B, S, S, 64, st))
