@@ -456,15 +456,11 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 #ifdef WIDE_T16
     if (g.TH == 16 && p.BN == 128) return launch_conv<T, CKB, 16, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
 #endif
-#ifdef NARROW_22
-    if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
-#else
     const bool one = (a.C0 + a.C1) * (int)sizeof(T) == CKB;
-#ifndef NO_ONE
-    if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1, true>(a, g.n_mtiles, st);
-#endif
+    // 64-wide outputs on 16x16 tiles: the single-chunk kernels (three blocks per CU share one L1) take the 2x2 wave
+    // layout, whose waves stream half the filter bytes each (e1b: +9..12 %); with several chunks the 4x1 layout wins
+    if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true>(a, g.n_mtiles, st);
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
-#endif
     if (g.TI == 1) {
         if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
         return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);

@@ -180,12 +180,13 @@ class BiDateEngine:
             ti, th, tw = 1, 8, 16
         n_mt = -(-n // ti) * -(-h // th) * -(-w // tw)
         bn = 128 if (not narrow and n_mt * (cout // 128) >= 512) else 64
-        wmn = '4,1' if th == 16 else '2,2'
         if self.precision == 'bf16':
             t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
         else:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
-        one = 'true' if th == 16 and (c0 + c1) * self.esize == ckb else 'false'    # single-chunk variant (3 blocks per CU)
+        single = th == 16 and (c0 + c1) * self.esize == ckb          # single-chunk variant (3 blocks per CU, 2x2 waves)
+        wmn = '4,1' if th == 16 and not single else '2,2'
+        one = 'true' if single else 'false'
         return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn},{one}>'
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
