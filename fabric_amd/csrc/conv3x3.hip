@@ -96,7 +96,7 @@ struct ConvCfg {
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
-__global__ __launch_bounds__(256, (ONE || (BN == 64 && TH == 8)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
@@ -462,6 +462,7 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true>(a, g.n_mtiles, st);
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
     if (g.TI == 1) {
+        if (p.BN == 128 && one) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2, true>(a, g.n_mtiles, st);
         if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
         return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
     }

@@ -184,7 +184,8 @@ class BiDateEngine:
             t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
         else:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
-        single = th == 16 and (c0 + c1) * self.esize == ckb          # single-chunk variant (3 blocks per CU, 2x2 waves)
+        # single-chunk variants (no next-chunk state): the 16x16 / 64-wide kernel and the 8x16 / 128-wide kernel
+        single = (c0 + c1) * self.esize == ckb and (th == 16 or (ti == 1 and bn == 128))
         wmn = '4,1' if th == 16 and not single else '2,2'
         one = 'true' if single else 'false'
         return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn},{one}>'
