@@ -74,7 +74,7 @@ def pmc_traffic(kernel, precision):
     if precision != 'bf16' or not os.path.exists(path):
         return None
     key = kernel.replace('bf16', 'unsigned short').replace(',', ', ')
-    rec = json.load(open(path)).get(key)
+    rec = json.load(open(path)).get(key)   # e.g. 'conv3x3_kernel<unsigned short, 128, ...>' or 'wgrad2_kernel<true>'
     if not rec:
         return None
     return {'unit': 'bytes/launch', 'hbm_read': rec['fetch_bytes_per_launch_corrected'],
@@ -139,7 +139,7 @@ def main():
     eng = model.engine()
     for _ in range(args.warmup):
         ts.step(x1, x2, lbl)
-    # Which conv3x3 instantiation dominates?  One fully instrumented, UNTIMED step decides (every event pair is a
+    # Which MFMA kernel (conv3x3 instantiation or weight-gradient GEMM) dominates?  One fully instrumented, UNTIMED step decides (every event pair is a
     # ~150 us pipeline bubble on this stack, so the timed region only brackets the launches of that one kernel,
     # and only during its first EVENT_STEPS steps).
     conv_all = None
@@ -195,7 +195,8 @@ def main():
                     'launches_per_step': n_dom, 'sampled_launches': cnt, 'sampling': 'one launch per timed step, round robin',
                     'avg_launch_us': secs / cnt * 1e6, 'rocprof_avg_launch_us': rocprof_avg_us(name, args.precision),
                     'flop_per_launch': flops / cnt,
-                    'all_conv3x3_launches': {'source': 'one fully instrumented untimed step',
+                    'all_mfma_kernels': {'source': 'one fully instrumented untimed step (conv3x3 fwd/dgrad + weight-gradient GEMMs)',
+                                             'per_kernel_ms': {k: round(v[2] * 1e3, 3) for k, v in sorted(conv_all.items(), key=lambda kv: -kv[1][2])},
                                              'seconds_per_step': conv_total,
                                              'achieved': sum(v[1] for v in conv_all.values()) / conv_total / 1e12}}
     if rank == 0:

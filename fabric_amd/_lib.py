@@ -25,6 +25,8 @@ SIGNATURES = {
     'bdn_conv3x3_num_mtiles': (_i, [_i, _i, _i, _i, _i]),
     'bdn_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_conv3x3_wgrad_ex': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_conv3x3_wgrad_variant': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_bn_finalize_workspace_bytes': (_sz, [_i, _i, _i]),
     'bdn_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),

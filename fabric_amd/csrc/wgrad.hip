@@ -531,12 +531,15 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     return BDN_OK;
 }
 
-extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
-                                 const void* in0, int C0, const void* in1, int C1,
-                                 int in_mode, const float* in_bn, int imgs_per_group,
-                                 float* partial, float* dw_oihw, int Cin_real,
-                                 int N, int H, int W, void* stream) {
+// phases: bit 0 = the split-K GEMM (partial tiles into `partial`), bit 1 = the fixed-order reduction of the partial
+// tiles into dw_oihw.  bdn_conv3x3_wgrad runs both; a profiler that wants the GEMM's own duration calls them apart.
+extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
+                                    const void* in0, int C0, const void* in1, int C1,
+                                    int in_mode, const float* in_bn, int imgs_per_group,
+                                    float* partial, float* dw_oihw, int Cin_real,
+                                    int N, int H, int W, int phases, void* stream) {
     if (!dz || !in0 || !partial || !dw_oihw) BDN_FAIL(BDN_E_ARG, "wgrad: null pointer");
+    if (!(phases & 3)) BDN_FAIL(BDN_E_ARG, "wgrad: phases must select the GEMM (1), the reduction (2) or both (3)");
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
         BDN_FAIL(BDN_E_SHAPE, "wgrad: bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
     if (Cout <= 0 || Cout % 64) BDN_FAIL(BDN_E_SHAPE, "wgrad: Cout=%d must be a multiple of 64", Cout);
@@ -554,8 +557,10 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles;
     a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc;
-    if (dtype == BDN_BF16) {
+    int rc = BDN_OK;
+    if (!(phases & 1)) {
+        if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
+    } else if (dtype == BDN_BF16) {
         // the pipelined kernel covers full 64-channel input tiles on 8x16 spatial tiles whose tensors stay below 2^31 elements
         const bool v2 = !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 &&
                         (size_t)N * H * W * (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1)) < ((size_t)1 << 31);
@@ -572,7 +577,28 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
         else rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1, false>(a, st) : launch_wgrad<float, 8, 8, 2, false>(a, st);
     } else BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
     if (rc) return rc;
-    launch_wgrad_reduce(partial, dw_oihw, p.S * (p.ksplit ? 2 : 1), Cout, Cin, Cin_real, st);
-    BDN_CHECK_LAUNCH("wgrad_reduce");
+    if (phases & 2) {
+        launch_wgrad_reduce(partial, dw_oihw, p.S * (p.ksplit ? 2 : 1), Cout, Cin, Cin_real, st);
+        BDN_CHECK_LAUNCH("wgrad_reduce");
+    }
     return BDN_OK;
 }
+
+extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
+                                 const void* in0, int C0, const void* in1, int C1,
+                                 int in_mode, const float* in_bn, int imgs_per_group,
+                                 float* partial, float* dw_oihw, int Cin_real,
+                                 int N, int H, int W, void* stream) {
+    return bdn_conv3x3_wgrad_ex(dtype, dz, Cout, in0, C0, in1, C1, in_mode, in_bn, imgs_per_group, partial, dw_oihw, Cin_real,
+                                N, H, W, 3, stream);
+}
+
+// which kernel the GEMM phase runs (bench.py names its roofline line after it): 2 = wgrad2 pipeline, 1 = simple kernel
+extern "C" int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || imgs_per_group <= 0) return 0;
+    const WgPlan p = wgrad_plan(N, H, W, Cout, C0 + C1, imgs_per_group);
+    const bool v2 = dtype == BDN_BF16 && !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 &&
+                    (size_t)N * H * W * (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1)) < ((size_t)1 << 31);
+    return v2 ? 2 : 1;
+}
+

@@ -383,14 +383,43 @@ class BiDateEngine:
                      ptr(sc['bnb']), ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
             return dz
 
+        def wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, stp):
+            """The weight-gradient GEMM and its reduction; with profiling on, the GEMM alone sits between two events
+            recorded on the stream it is launched on."""
+            args = (self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
+                    ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
+            name = None
+            if self.prof is not None:
+                v = _lib.load().bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg)
+                if v == 2:
+                    name = f'wgrad2_kernel<{"true" if mode == IN_BNRELU else "false"}>'
+                else:
+                    small = wk <= 8 and hk <= 8 and ipg % 2 == 0
+                    name = (f'wgrad_kernel<{"bf16" if self.precision == "bf16" else "f32"},8,{"8,2" if small else "16,1"},'
+                            f'{"true" if c0 + c1 <= 32 else "false"}>')
+                if self.prof_filter is not None and name != self.prof_filter:
+                    name = None
+                elif self.prof_pick is not None:
+                    self._prof_seen += 1
+                    if self._prof_seen - 1 != self.prof_pick:
+                        name = None
+            if name is None:
+                call('bdn_conv3x3_wgrad_ex', *args, 3, stp)
+                return
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call('bdn_conv3x3_wgrad_ex', *args, 1, stp)
+            e1.record()
+            call('bdn_conv3x3_wgrad_ex', *args, 2, stp)
+            self.prof.append((name, 2.0 * n * hk * wk * L.cout * 9 * (c0 + c1), e0, e1))
+
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
             if self._diag_skip_wgrad:                # tools/ab_step.py diagnostic only: how long is the dz chain alone?
                 return
             hk, wk = ws.dims[L.level - 1]
             keys = [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias']
             if side is None:
-                call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
-                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, st)
+                wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, st)
                 if zero_bias_grads:                  # feeds a BatchNorm: gradient is identically zero
                     grads[f'{L.conv}.bias'].zero_()
                 ready(keys)
@@ -399,8 +428,7 @@ class BiDateEngine:
             ev.record(main)                          # dz, the BatchNorm gradients and everything before them
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                call('bdn_conv3x3_wgrad', self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
-                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, side.cuda_stream)
+                wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, side.cuda_stream)
                 if zero_bias_grads:
                     grads[f'{L.conv}.bias'].zero_()
                 ready(keys)                          # a bucket all-reduce launched here is ordered behind this wgrad

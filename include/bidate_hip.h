@@ -90,6 +90,14 @@ int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
                       int in_mode, const float* in_bn, int imgs_per_group,
                       float* partial, float* dw_oihw, int Cin_real,
                       int N, int H, int W, void* stream);
+/* The same in two phases (phases bit 0: split-K GEMM into `partial`; bit 1: fixed-order reduction into dw_oihw), so that
+ * a profiler can bracket the GEMM alone; and which GEMM kernel a shape gets (2 = software-pipelined wgrad2, 1 = simple). */
+int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
+                         const void* in0, int C0, const void* in1, int C1,
+                         int in_mode, const float* in_bn, int imgs_per_group,
+                         float* partial, float* dw_oihw, int Cin_real,
+                         int N, int H, int W, int phases, void* stream);
+int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group);
 
 /* ---- BatchNorm2d training statistics: nn.BatchNorm2d, models/unet_parts.py:14,17 ----
  * Reduces the conv's per-tile partials and produces, per group g and channel c,
