@@ -408,16 +408,19 @@ __global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
 #undef WG_ROW
 #undef WG_CHUNK
 
-    // partial[split][tap][co][ci]
+    // partial[split][tap][co][ci]: one uniform base per (tap, row group) + the lane's fixed element offset, so the 144
+    // stores need no per-store 64-bit address arithmetic (it was a thousand VALU instructions per block)
     const int ci = ci0 + wn * 32 + l31;
     if (ci < Cin) {
+        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);                 // elements; co0 is in the base
+        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++)
+        for (int tap = 0; tap < 9; tap++) {
+            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;                 // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                a.partial[(((size_t)split * 9 + tap) * a.Cout + co) * Cin + ci] = acc[tap][r];
-            }
+            for (int r = 0; r < 16; r++)
+                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
+        }
     }
 }
 
