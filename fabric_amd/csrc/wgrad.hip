@@ -490,6 +490,9 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
     }
 }
 
+#ifndef WG_SIMPLE_MULT
+#define WG_SIMPLE_MULT 2
+#endif
 static int g_wgrad_blocks = 256;      // bdn_set_tuning(BDN_TUNE_WGRAD_BLOCKS): target grid size of the weight-gradient GEMM
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; };
 static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
@@ -498,7 +501,9 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
     p.n_cot = Cout / 64;
     p.n_cit = (Cin + 63) / 64;
     const int tiles = p.n_cot * p.n_cit;
-    int S = (g_wgrad_blocks + tiles - 1) / tiles;                      // ~256 blocks: the kernel runs beside the dgrad chain on a second stream, so
+    // the simple kernel (first layer / 8x8 maps) has no software pipeline: it hides latency with a second block per CU
+    const bool simple = Cin <= 32 || p.g.TI != 1;
+    int S = ((simple ? WG_SIMPLE_MULT : 1) * g_wgrad_blocks + tiles - 1) / tiles;                      // ~256 blocks: the kernel runs beside the dgrad chain on a second stream, so
                                                             // a smaller partial-sum footprint beats more parallelism (A/B: 512 -> 256 = -2.7 % step)
     if (S > p.g.n_mtiles) S = p.g.n_mtiles;
     if (S < 1) S = 1;
