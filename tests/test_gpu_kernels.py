@@ -517,3 +517,37 @@ def test_product_pool_equals_separate_kernels(prec, shape):
     _lib.call('bdn_product_pool', dt, z_d.data_ptr(), bn_d.data_ptr(), f2.data_ptr(), p2.data_ptr(), B, H, W, C, st())
     torch.cuda.synchronize()
     assert torch.equal(f1, f2) and torch.equal(p1, p2)
+
+
+def test_wgrad_phases_variant_and_tuning_knob():
+    """bdn_conv3x3_wgrad_ex(phases 1 then 2) == bdn_conv3x3_wgrad; the grid-size knob changes the workspace, not the result
+    beyond the summation order of the partial tiles; bdn_conv3x3_wgrad_variant names the kernel family."""
+    lib = _lib.load()
+    N, H, W, Cout, C0, ipg = 16, 32, 32, 128, 64, 8
+    dt, td = DT['bf16']
+    dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 91)))
+    x = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 92)))
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg) == 2          # pipelined wgrad2
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, 16, 0, ipg) == 1          # narrow input: simple kernel
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, 8, 8, Cout, C0, 0, ipg) == 1          # 8x8 maps: simple kernel
+    res = {}
+    try:
+        for blocks in (256, 64):
+            _lib.call('bdn_set_tuning', 1, blocks)
+            part = torch.empty(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg) // 4, device='cuda')
+            a = torch.empty(Cout, C0, 3, 3, device='cuda')
+            b = torch.full_like(a, float('nan'))
+            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+                      part.data_ptr(), a.data_ptr(), C0, N, H, W, st())
+            for ph in (1, 2):
+                _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+                          part.data_ptr(), b.data_ptr(), C0, N, H, W, ph, st())
+            torch.cuda.synchronize()
+            assert torch.equal(a, b)
+            res[blocks] = (a.cpu(), part.numel())
+    finally:
+        _lib.call('bdn_set_tuning', 1, 256)
+    assert res[64][1] < res[256][1]
+    assert_close('dw across grid sizes', res[64][0], res[256][0], 1e-5)
+    with pytest.raises(RuntimeError):
+        _lib.call('bdn_set_tuning', 99, 1)
