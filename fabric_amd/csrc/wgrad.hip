@@ -438,6 +438,233 @@ static int launch_wgrad2(const WgradArgs& a, hipStream_t st) {
     return BDN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad3: the same pipeline with EIGHT waves per block (two per SIMD) on a 128(co) x 64(ci) tile.  The BatchNorm'd
+// activation patch is staged once for four co-waves instead of two, so the staging work per MFMA (the 40 % of wgrad2's
+// time that is not MFMA + LDS reads) drops by a third, and the second wave of every SIMD issues into the other's
+// staging instructions.  One register set (256 registers per wave), refilled in two stages: the patch units right after
+// their last LDS store (row 4), the dz units after theirs (row 9).  LDS: 2 x (192 x 192 B patch + 128 x 320 B dz) = 152 KB.
+struct Wg3 {
+    static constexpr int PW = 18, PH = 10, STR = 192, DSTR = 320;
+    static constexpr int PATCH_BYTES = 3 * 64 * STR;             // 180 patch pixels padded to the 192 unit slots the threads own
+    static constexpr int DZ_BYTES = 128 * DSTR;                  // 256 B of dz per pixel + 64 B so that four pixels cover all banks
+    static constexpr int BUF = PATCH_BYTES + DZ_BYTES;
+    static constexpr int SMEM = 2 * BUF;
+};
+
+template <bool USE_BN>
+__global__ __launch_bounds__(512, 1) void wgrad3_kernel(WgradArgs a) {
+    constexpr int PW = Wg3::PW, STR = Wg3::STR, DSTR = Wg3::DSTR, BUF = Wg3::BUF, PATCH_BYTES = Wg3::PATCH_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) of 128 x ci [wn*32,+32) of 64
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.n_cot * a.n_cit;                      // n_cot counts 128-wide tiles here
+    const int tile = logical % ntile, split = logical / ntile;
+    const int co0 = (tile / a.n_cit) * 128, ci0 = (tile % a.n_cit) * 64;
+    const int Cin = a.C0 + a.C1;
+
+    const bf16s* src; int Csrc, cs;
+    if (ci0 < a.C0) { src = reinterpret_cast<const bf16s*>(a.in0); Csrc = a.C0; cs = ci0; }
+    else { src = reinterpret_cast<const bf16s*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
+    const bf16s* dzp = reinterpret_cast<const bf16s*>(a.dz);
+
+    // ---- staging ownership.  Patch: thread = (pixel lane tid>>3 of 64, unit tid&7), units i = 0..2 at pixel + 64 i.
+    //      dz: thread = (pixel lane tid>>4 of 32, unit tid&15 of the 16 units of 128 channels), units i = 0..3 at pixel + 32 i.
+    const int u_pix = tid >> 3, sub_e = (tid & 7) * 8;
+    const unsigned wbase = u_pix * STR + (tid & 7) * 16;
+    const int d_pix = tid >> 4, dsub_e = (tid & 15) * 8;
+    const unsigned dbase = PATCH_BYTES + d_pix * DSTR + (tid & 15) * 16;
+    int pyx[3];
+    unsigned poff[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int pix = u_pix + 64 * i, yy = pix / PW, xx = pix % PW;
+        pyx[i] = pix < Wg3::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
+        poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub_e) * 2);
+    }
+    const unsigned poff_c = (unsigned)(((a.W + 1) * Csrc + cs + sub_e) * 2);          // the tile's origin pixel: always inside
+    const int dpx = d_pix & 15, dpy0 = d_pix >> 4;             // dz units: tile pixel (dpy0 + 2 i, dpx)
+    const unsigned drow = (unsigned)(a.W * a.Cout * 2);
+    const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + dsub_e) * 2);
+    const unsigned doff_c = (unsigned)((co0 + dsub_e) * 2);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    uint4 pR[3], dR[4];                                        // the prefetch register set (patch part, dz part)
+    unsigned mP = 0, mD = 0;
+    int gP = 0, cur_grp = -1;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
+
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    int lq = q_begin;                                          // load cursor: chunk index and its tile coordinates
+    int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
+    int lg = ln / a.imgs_per_group;
+    int lpix = 0, ly0 = 0, lx0 = 0;
+    bool llive = false;
+
+    // patch part of the next chunk in sequence (advances the cursor; the dz part of the same chunk follows later)
+#define W3_LOAD_P()                                                                                      \
+    {                                                                                                   \
+        llive = lq < q_end;                                                                             \
+        ly0 = lty * 8; lx0 = ltx * 16;                                                                  \
+        if (llive) { lpix = (ln * a.H + ly0) * a.W + lx0; gP = lg; }                                    \
+        const unsigned char* sp_ = reinterpret_cast<const unsigned char*>(src) + ((long)(lpix - a.W - 1) * Csrc) * 2; \
+        unsigned m_ = 0;                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                  \
+            const int y_ = ly0 + (pyx[i] >> 16), x_ = lx0 + (short)(pyx[i] & 0xffff);                   \
+            const bool ok_ = llive && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;     \
+            pR[i] = *reinterpret_cast<const uint4*>(sp_ + (ok_ ? poff[i] : poff_c));                    \
+            m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
+        }                                                                                               \
+        mP = m_;                                                                                        \
+        if (llive) {                                                                                    \
+            lq++;                                                                                       \
+            if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
+        }                                                                                               \
+    }
+#define W3_LOAD_D()                                                                                      \
+    {                                                                                                   \
+        const unsigned char* dp_ = reinterpret_cast<const unsigned char*>(dzp) + ((long)lpix * a.Cout) * 2; \
+        unsigned m_ = 0;                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
+            const bool ok_ = llive && (ly0 + dpy0 + 2 * i) < a.H && (lx0 + dpx) < a.W;                  \
+            dR[i] = *reinterpret_cast<const uint4*>(dp_ + (ok_ ? doff0 + (unsigned)(2 * i) * drow : doff_c)); \
+            m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
+        }                                                                                               \
+        mD = m_;                                                                                        \
+    }
+#define W3_GROUP(g_)                                                                                     \
+    if (USE_BN && (g_) != cur_grp) {                                                                    \
+        cur_grp = (g_);                                                                                 \
+        const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub_e;                              \
+        const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub_e;                              \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }                \
+    }
+#define W3_ST_P(i_, wb_)                                                                                 \
+    {                                                                                                   \
+        uint4 v_ = pR[i_];                                                                              \
+        if (USE_BN) v_ = bnrelu_unit<bf16s>(v_, sc, sh);                                                \
+        const bool ok_ = (mP >> (i_)) & 1u;                                                             \
+        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+        *reinterpret_cast<uint4*>((wb_) + wbase + (i_) * 64 * STR) = v_;                                \
+    }
+#define W3_ST_D(i_, wb_)                                                                                 \
+    {                                                                                                   \
+        uint4 v_ = dR[i_];                                                                              \
+        const bool ok_ = (mD >> (i_)) & 1u;                                                             \
+        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+        *reinterpret_cast<uint4*>((wb_) + dbase + (i_) * 32 * DSTR) = v_;                               \
+    }
+
+    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int kpix = (lane & 15) >> 2;
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * DSTR + wm * 64 + chan_b;    // + ks*16*DSTR (+4*DSTR)
+    const unsigned b_base = (half * 8 + kpix) * STR + wn * 64 + chan_b;                   // + (pr*PW + c)*STR (+4*STR)
+    uint4 af[4], bq[2][3];
+#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
+#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * DSTR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * DSTR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + b_base + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + b_base + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
+#define W3_ROW(pr_, ...)                                                                                 \
+    {                                                                                                   \
+        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
+        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) }                     \
+        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
+        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) }       \
+        __VA_ARGS__                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+    // one chunk: compute from buffer rb_; the register set (chunk q+1) goes into buffer wb_ and is refilled with chunk q+2
+#define W3_CHUNK(rb_, wb_)                                                                               \
+    {                                                                                                   \
+        const unsigned char* rb = (rb_);                                                                \
+        unsigned char* wb = (wb_);                                                                      \
+        W3_GROUP(gP)                                                                                    \
+        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)                        \
+        W3_ROW(0, )                                                                                     \
+        W3_ROW(1, W3_ST_P(0, wb))                                                                       \
+        W3_ROW(2, W3_ST_P(1, wb))                                                                       \
+        W3_ROW(3, W3_ST_P(2, wb))                                                                       \
+        W3_ROW(4, W3_LOAD_P())                                                                          \
+        W3_ROW(5, W3_ST_D(0, wb))                                                                       \
+        W3_ROW(6, W3_ST_D(1, wb))                                                                       \
+        W3_ROW(7, W3_ST_D(2, wb))                                                                       \
+        W3_ROW(8, W3_ST_D(3, wb))                                                                       \
+        W3_ROW(9, W3_LOAD_D())                                                                          \
+    }
+
+    unsigned char* buf0 = smem;
+    unsigned char* buf1 = smem + BUF;
+    if (q_begin < q_end) {
+        W3_LOAD_P() W3_LOAD_D()
+        W3_GROUP(gP)
+#pragma unroll
+        for (int i = 0; i < 3; i++) W3_ST_P(i, buf0)
+#pragma unroll
+        for (int i = 0; i < 4; i++) W3_ST_D(i, buf0)
+        W3_LOAD_P() W3_LOAD_D()
+        __syncthreads();
+        for (int q = q_begin; q < q_end; q += 2) {
+            W3_CHUNK(buf0, buf1)
+            __syncthreads();
+            W3_CHUNK(buf1, buf0)                              // an odd tail runs on an all-zero chunk (masks are clear past q_end)
+            __syncthreads();
+        }
+    }
+#undef W3_LOAD_P
+#undef W3_LOAD_D
+#undef W3_GROUP
+#undef W3_ST_P
+#undef W3_ST_D
+#undef TRP
+#undef LDA
+#undef LDB
+#undef WG_MMA
+#undef W3_ROW
+#undef W3_CHUNK
+
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
+        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
+        }
+    }
+}
+
+template <bool USE_BN>
+static int launch_wgrad3(const WgradArgs& a, hipStream_t st) {
+    auto kern = wgrad3_kernel<USE_BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg3::SMEM);
+        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad3: hipFuncSetAttribute(%d): %s", Wg3::SMEM, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(512), Wg3::SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad3");
+    return BDN_OK;
+}
+
 // dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
 // Block = SL split lanes x (256/SL) (co,ci) pairs: reads are coalesced along ci, the SL lanes walk the
 // splits in parallel (fixed order -> deterministic), an LDS tree combines them, and each pair's nine taps
@@ -494,11 +721,24 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 #define WG_SIMPLE_MULT 2
 #endif
 static int g_wgrad_blocks = 256;      // bdn_set_tuning(BDN_TUNE_WGRAD_BLOCKS): target grid size of the weight-gradient GEMM
-struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; };
+static int g_wgrad_v3 = 0;           // bdn_set_tuning(BDN_TUNE_WGRAD_V3): 1 = eight-wave kernel where the shape allows it.  Off by default:
+                                     // -4 % on the weight gradients alone, but its blocks fill every wave slot of a CU, the dz chain can no longer
+                                     // run beside it, and the training step gets 1.9 % SLOWER (tools/ab_wgblocks.py 0,1 2)
+struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; bool v3; };
 static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
     WgPlan p;
     p.g = pick_tile(N, H, W, imgs_per_group);
-    p.n_cot = Cout / 64;
+    // eight-wave 128x64-tile kernel: where the shape allows it and every block still gets at least 16 chunks (with
+    // fewer, the wider tile's prologue / epilogue outweighs its cheaper staging: d1b, d2b stay on wgrad2)
+    p.v3 = g_wgrad_v3 && Cout % 128 == 0 && Cin > 32 && Cin % 64 == 0 && p.g.TI == 1;
+    if (p.v3) {
+        const int t3 = (Cout / 128) * ((Cin + 63) / 64);
+        int s3 = (g_wgrad_blocks + t3 - 1) / t3;
+        if (s3 > p.g.n_mtiles) s3 = p.g.n_mtiles;
+        if (s3 < 1) s3 = 1;
+        if ((p.g.n_mtiles + s3 - 1) / s3 < 16) p.v3 = false;
+    }
+    p.n_cot = p.v3 ? Cout / 128 : Cout / 64;
     p.n_cit = (Cin + 63) / 64;
     const int tiles = p.n_cot * p.n_cit;
     // the simple kernel (first layer / 8x8 maps) has no software pipeline: it hides latency with a second block per CU
@@ -515,6 +755,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
 
 extern "C" int bdn_set_tuning(int key, int value) {
     if (key == BDN_TUNE_WGRAD_BLOCKS && value >= 1 && value <= 4096) { g_wgrad_blocks = value; return BDN_OK; }
+    if (key == BDN_TUNE_WGRAD_V3 && (value == 0 || value == 1)) { g_wgrad_v3 = value; return BDN_OK; }
     BDN_FAIL(BDN_E_ARG, "set_tuning: unknown key %d or value %d out of range", key, value);
 }
 
@@ -577,7 +818,8 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
 #else
         const bool use_v2 = v2;
 #endif
-        if (use_v2) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
+        if (use_v2 && p.v3 && C0 % 64 == 0) rc = a.in_bn ? launch_wgrad3<true>(a, st) : launch_wgrad3<false>(a, st);
+        else if (use_v2) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
         else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);
     } else if (dtype == BDN_F32) {

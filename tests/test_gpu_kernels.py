@@ -551,3 +551,28 @@ def test_wgrad_phases_variant_and_tuning_knob():
     assert_close('dw across grid sizes', res[64][0], res[256][0], 1e-5)
     with pytest.raises(RuntimeError):
         _lib.call('bdn_set_tuning', 99, 1)
+
+
+def test_wgrad3_eight_wave_variant_matches_wgrad2():
+    """BDN_TUNE_WGRAD_V3: the 128x64-tile, eight-wave kernel gives wgrad2's result up to the summation order of the splits
+    (ragged map, BatchNorm'd input, two statistic groups)."""
+    lib = _lib.load()
+    N, H, W, Cout, C0, ipg = 8, 40, 50, 256, 128, 4
+    dt, td = DT['bf16']
+    dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 95)))
+    x = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 96)))
+    bn_d = dev(bn_table(N // ipg, C0, 97))
+    out = {}
+    try:
+        for v in (0, 1):
+            _lib.call('bdn_set_tuning', 2, v)
+            part = torch.empty(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg) // 4, device='cuda')
+            dw = torch.full((Cout, C0, 3, 3), float('nan'), device='cuda')
+            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_BNRELU, bn_d.data_ptr(), ipg,
+                      part.data_ptr(), dw.data_ptr(), C0, N, H, W, st())
+            torch.cuda.synchronize()
+            out[v] = dw.cpu()
+    finally:
+        _lib.call('bdn_set_tuning', 2, 0)
+    assert torch.isfinite(out[1]).all()
+    assert_close('wgrad3 vs wgrad2', out[1], out[0], 2e-6)
