@@ -203,8 +203,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 //    72), and the reads of row pr+1 are issued ahead of the MFMAs of row pr;
 //  * every LDS read is one base register + an immediate offset, staging is branch free (masks, clamped
 //    addresses) and is spread over the rows so its VALU work sits in the shadow of the MFMAs.
+// LDS pixel stride: 128 B (the 64 channels, no padding) with a swizzle instead of the 192-byte padded stride: the two
+// 64-byte halves of a pixel row are swapped when bit 1 of the pixel index is set.  A transposing read touches four
+// consecutive pixels x one 64-byte half; with the swap their windows land on the four distinct bank quarters
+// (quarter = (2p + (h ^ bit1(p))) mod 4), so the reads stay conflict-free and a buffer pair takes 80 KB instead of 120 KB:
+// a second kernel's blocks fit beside this one's on a CU.
 struct Wg2 {
-    static constexpr int PW = 18, PH = 10, STR = 192;
+    static constexpr int PW = 18, PH = 10, STR = 128;
     static constexpr int PATCH_BYTES = 6 * 32 * STR;             // 180 patch pixels, padded to the 192 unit slots the staging threads own
     static constexpr int DZ_BYTES = 128 * STR;
     static constexpr int BUF = PATCH_BYTES + DZ_BYTES;
@@ -237,7 +242,8 @@ __global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
 
     // ---- staging ownership: thread = (pixel lane u_pix, 16-byte channel unit sub); units i = u_pix + 32 i
     const int u_pix = tid >> 3, sub = tid & 7, sub_e = sub * 8;
-    const unsigned wbase = u_pix * STR + sub * 16;             // LDS offset of unit 0; unit i adds i*32*STR
+    // LDS offset of unit 0 (unit i adds i*32*STR: 32 pixels further, same swizzle since bit 1 of the pixel index is unchanged)
+    const unsigned wbase = u_pix * STR + ((sub ^ (((u_pix >> 1) & 1) << 2)) * 16);
     int pyx[6];                                                // patch units: (y-1, x-1) relative to the tile origin
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -338,12 +344,17 @@ __global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
     // (lane&3) of 16-channel block ((lane>>4)&1) of the wave's 32 channels
     const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int kpix = (lane & 15) >> 2;
-    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + wm * 64 + chan_b;     // + ks*16*STR (+4*STR)
-    const unsigned b_base = (half * 8 + kpix) * STR + wn * 64 + chan_b;                   // + (pr*PW + c)*STR (+4*STR)
+    // dz rows: pixel index ks*16 + half*8 + kpix (+4): bit 1 is bit 1 of kpix -> one swizzled base
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;   // + ks*16*STR (+4*STR)
+    // patch rows: pixel index pr*18 + 8*half + kpix + c (+4): bit 1 is bit 1 of (kpix + m), m = (c + 2 pr) & 3 -> four bases
+    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
+    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
+    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
+#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
     uint4 af[4], bq[2][3];
 #define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
 #define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + b_base + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + b_base + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
 #define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
     // patch row pr_: prefetch the fragments of row pr_+1 (and dz row pr_+1), then the MFMAs of every (tile row, r)
     // pair that reads patch row pr_, then this row's share of the staging (STG_)
@@ -404,6 +415,7 @@ __global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
 #undef TRP
 #undef LDA
 #undef LDB
+#undef B_BASE
 #undef WG_MMA
 #undef WG_ROW
 #undef WG_CHUNK
@@ -722,8 +734,8 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 #endif
 static int g_wgrad_blocks = 256;      // bdn_set_tuning(BDN_TUNE_WGRAD_BLOCKS): target grid size of the weight-gradient GEMM
 static int g_wgrad_v3 = 0;           // bdn_set_tuning(BDN_TUNE_WGRAD_V3): 1 = eight-wave kernel where the shape allows it.  Off by default:
-                                     // -4 % on the weight gradients alone, but its blocks fill every wave slot of a CU, the dz chain can no longer
-                                     // run beside it, and the training step gets 1.9 % SLOWER (tools/ab_wgblocks.py 0,1 2)
+                                     // -4 % on the weight gradients alone, but half the tiles means twice the splits and twice the partial-tile
+                                     // traffic, and the training step gets 1.9 % SLOWER (tools/ab_wgblocks.py 0,1 2)
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; bool v3; };
 static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
     WgPlan p;
