@@ -78,7 +78,8 @@ def pmc_traffic(kernel, precision):
     if not rec:
         return None
     return {'unit': 'bytes/launch', 'hbm_read': rec['fetch_bytes_per_launch_corrected'],
-            'hbm_write': rec['write_bytes_per_launch'], 'source': 'profiles/r1_pmc_traffic.json'}
+            'hbm_write': rec['write_bytes_per_launch'], 'source': 'profiles/r1_pmc_traffic.json',
+            'correction': 'FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported; separate --pmc passes'}
 
 
 def rocprof_avg_us(kernel, precision):
@@ -191,7 +192,9 @@ def main():
         achieved = flops / secs
         conv_total = sum(v[2] for v in conv_all.values())
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved / 1e12, 'peak': peak / 1e12,
-                    'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_traffic(name, args.precision),
+                    'unit': 'TFLOP/s', 'frac': achieved / peak,
+                    'traffic': (lambda t: None if t is None else t['hbm_read'] + t['hbm_write'])(pmc_traffic(name, args.precision)),
+                    'traffic_detail': pmc_traffic(name, args.precision),
                     'launches_per_step': n_dom, 'sampled_launches': cnt, 'sampling': 'one launch per timed step, round robin',
                     'avg_launch_us': secs / cnt * 1e6, 'rocprof_avg_launch_us': rocprof_avg_us(name, args.precision),
                     'flop_per_launch': flops / cnt,
