@@ -462,8 +462,10 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true>(a, g.n_mtiles, st);
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
     if (g.TI == 1) {
-        if (p.BN == 128 && one) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2, true>(a, g.n_mtiles, st);
-        if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
+        // 128-wide column tiles: 1x4 waves (each 128 pixels x 32 channels) stream half the filter bytes of the 2x2 layout
+        // through the L1 and need half the ring registers; the A fragments are read from LDS by all four (+1.5 % overall)
+        if (p.BN == 128 && one) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, true>(a, g.n_mtiles, st);
+        if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4>(a, g.n_mtiles, st);
         return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
     }
     if (p.BN == 128) return launch_conv<T, CKB, 8, 8, 2, 128, 2, 2>(a, g.n_mtiles, st);

@@ -186,7 +186,7 @@ class BiDateEngine:
             t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
         # single-chunk variants (no next-chunk state): the 16x16 / 64-wide kernel and the 8x16 / 128-wide kernel
         single = (c0 + c1) * self.esize == ckb and (th == 16 or (ti == 1 and bn == 128))
-        wmn = '4,1' if th == 16 and not single else '2,2'
+        wmn = '4,1' if th == 16 and not single else ('1,4' if (ti == 1 and th == 8 and bn == 128) else '2,2')
         one = 'true' if single else 'false'
         return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn},{one}>'
 
