@@ -407,9 +407,19 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
     }
 }
 
+// bdn_conv3x3_variant: the dispatcher below runs as usual but, instead of launching, the chosen instantiation writes
+// its name here (one source of truth for profilers that have to match rocprofv3 kernel names)
+static thread_local bool g_conv_query = false;
+static thread_local char g_conv_variant[160];
+
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE>;
+    if (g_conv_query) {
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s>",
+                 sizeof(T) == 2 ? "bf16" : "f32", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false");
+        return BDN_OK;
+    }
     auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -519,6 +529,16 @@ extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, 
                            int N, int H, int W, int Cout, void* stream) {
     return conv3x3_impl(dtype, in0, C0, in1, C1, in_mode, in_bn, imgs_per_group, w, bias, out, stats_partial,
                         nullptr, nullptr, N, H, W, Cout, stream);
+}
+
+extern "C" const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group) {
+    g_conv_variant[0] = 0;
+    g_conv_query = true;
+    void* dummy = reinterpret_cast<void*>(16);             // never dereferenced: nothing is launched in query mode
+    const int rc = conv3x3_impl(dtype, dummy, C0, C1 ? dummy : nullptr, C1, BDN_IN_PLAIN, nullptr, imgs_per_group, dummy, nullptr, dummy,
+                                nullptr, nullptr, nullptr, N, H, W, Cout, nullptr);
+    g_conv_query = false;
+    return rc == BDN_OK ? g_conv_variant : "";
 }
 
 extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad, void* dA,

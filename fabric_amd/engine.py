@@ -170,25 +170,8 @@ class BiDateEngine:
 
     # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
     def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg):
-        """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to (csrc/conv3x3.hip)."""
-        narrow = cout % 128 != 0
-        if w <= 8 and h <= 8 and ipg % 2 == 0:
-            ti, th, tw = 2, 8, 8
-        elif narrow and h >= 12 and w >= 12:
-            ti, th, tw = 1, 16, 16
-        else:
-            ti, th, tw = 1, 8, 16
-        n_mt = -(-n // ti) * -(-h // th) * -(-w // tw)
-        bn = 128 if (not narrow and n_mt * (cout // 128) >= 512) else 64
-        if self.precision == 'bf16':
-            t, ckb = 't', (128 if c0 % 64 == 0 and c1 % 64 == 0 else 32)
-        else:
-            t, ckb = 'f', (128 if c0 % 32 == 0 and c1 % 32 == 0 else 64)
-        # single-chunk variants (no next-chunk state): the 16x16 / 64-wide kernel and the 8x16 / 128-wide kernel
-        single = (c0 + c1) * self.esize == ckb and (th == 16 or (ti == 1 and bn == 128))
-        wmn = '4,1' if th == 16 and not single else ('1,4' if (ti == 1 and th == 8 and bn == 128) else '2,2')
-        one = 'true' if single else 'false'
-        return f'conv3x3_kernel<{"bf16" if t == "t" else "f32"},{ckb},{th},{tw},{ti},{bn},{wmn},{one}>'
+        """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to: asked from the library's own dispatcher."""
+        return _lib.load().bdn_conv3x3_variant(self.dt, n, h, w, c0, c1, cout, ipg).decode()
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
         name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
