@@ -3,7 +3,11 @@ validation pass that reports the reference's metrics -- per-batch accuracy and s
 precision / recall / F1, averaged over batches (utils/helpers.py:45-59).  Tracking SaaS clients (comet,
 polyaxon), the GCS download and checkpoint upload of the reference are out of scope.
 
-    python -m fabric_amd.train --synthetic --epochs 1          # needs an MI355X
+    python -m fabric_amd.train --synthetic --epochs 1                                   # needs an MI355X
+    python -m fabric_amd.train --metadata metadata.json --dataset_dir ./onera/          # an OSCD directory tree
+
+With real data the loop also does what train.py:182-205 does after validation: the full validation scenes are
+predicted tile by tile (utils/inference.py) -- here on the device-resident city stacks -- and written as PNG masks.
 """
 import argparse
 import json
@@ -20,7 +24,7 @@ from .utils.metrics import TverskyLoss, batch_prf_from_counts
 
 DEFAULTS = dict(patch_size=90, stride=180, augmentation=True, num_workers=2, epochs=1, batch_size=32,
                 learning_rate=1e-3, loss_function='tversky', tversky_alpha=0.1, tversky_beta=0.9,
-                validation_cities=['cupertino', 'rennes'])          # reference metadata.json:32-48
+                validation_cities=['cupertino', 'rennes'], dataset_dir='./onera/', log_dir='./log/')   # reference metadata.json:32-48
 
 
 def make_loaders(full_load, val_cities, patch_size, stride, batch_size, augmentation, num_workers=0,
@@ -80,20 +84,48 @@ def main(argv=None):
             ap.add_argument(f'--{k}', type=type(v), default=v)
     ap.add_argument('--synthetic', action='store_true', help='use fabric_amd.utils.dataloaders.synthetic_onera()')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--metadata', default=None, help="JSON in the reference's metadata.json schema (band_ids, band_means, "
+                                                     "band_stds, ...): its entries become defaults like utils/parser.py:7-10")
+    pre, _ = ap.parse_known_args(argv)
+    meta = {}
+    if pre.metadata:
+        with open(pre.metadata) as fh:
+            meta = json.load(fh)
+        ap.set_defaults(**{k: v for k, v in meta.items() if k in DEFAULTS})
     opt = ap.parse_args(argv)
-    if not opt.synthetic:
-        raise SystemExit('only --synthetic data is available here (GeoTIFF ingest needs rasterio/cv2; SURVEY.md 8f n3)')
+    for k in ('band_ids', 'band_means', 'band_stds'):
+        setattr(opt, k, meta.get(k))
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
-    data = synthetic_onera(n_cities=6, bands=13, size=(360, 360))
-    val_cities = ['city4', 'city5']
-    train_loader, val_loader = make_loaders(data, val_cities, opt.patch_size, opt.stride // 2, opt.batch_size, opt.augmentation)
-    model = BiDateNet(13, 2, precision=opt.precision).to(dev)
+    scenes = None
+    if opt.synthetic:
+        data = synthetic_onera(n_cities=6, bands=13, size=(360, 360))
+        val_cities = ['city4', 'city5']
+    else:
+        if not opt.band_ids:
+            raise SystemExit('real data needs --metadata with band_ids / band_means / band_stds (the reference keeps them in '
+                             'metadata.json); or use --synthetic')
+        from .utils import ingest
+        scenes = ingest.full_onera_loader(opt.dataset_dir, opt, device=dev)      # city stacks stay in HBM for the scene pass
+        data = {c: {'images': d['images'].cpu().numpy(), 'labels': d['labels']} for c, d in scenes.items()}
+        val_cities = [c for c in opt.validation_cities if c in data]
+    train_loader, val_loader = make_loaders(data, val_cities, opt.patch_size, opt.stride // 2 if opt.synthetic else opt.stride,
+                                            opt.batch_size, opt.augmentation)
+    model = BiDateNet(len(opt.band_ids) if opt.band_ids else 13, 2, precision=opt.precision).to(dev)
     step = TrainStep(model, lr=opt.learning_rate, tversky_alpha=opt.tversky_alpha, tversky_beta=opt.tversky_beta)
     for epoch in range(opt.epochs):
         tr = train_epoch(step, train_loader, dev, opt.patch_size)
         va = validate(model, val_loader, dev, opt.patch_size, opt.tversky_alpha, opt.tversky_beta)
         print(json.dumps({'epoch': epoch, **{'train_' + k: float(v) for k, v in tr.items()},
                           **{'validate_' + k: float(v) for k, v in va.items()}}))
+        if scenes is not None:                                 # train.py:182-205: full validation images
+            from .utils import ingest
+            from .utils.inference import predict_scene
+            os.makedirs(opt.log_dir, exist_ok=True)
+            model.eval()
+            for city in val_cities:
+                st = scenes[city]['images']
+                mask = predict_scene(model, st[0], st[1], patch_size=opt.patch_size, batch_size=opt.batch_size)
+                ingest.write_png_gray(os.path.join(opt.log_dir, f'{city}_epoch_{epoch}.png'), (mask * 255).cpu().numpy())
 
 
 if __name__ == '__main__':

@@ -93,3 +93,23 @@ def test_full_onera_loader_and_generate_patches(tmp_path):
     # the reference's dataloaders names resolve to the ingest module
     from fabric_amd.utils import dataloaders as dl
     assert dl.city_loader is ing.city_loader and dl.get_train_val_metadata is ing.get_train_val_metadata
+
+
+def test_train_loop_on_an_oscd_directory(tmp_path, capsys):
+    """python -m fabric_amd.train on a (synthetic) OSCD tree: ingest -> patch loaders -> fused steps -> validation ->
+    full-scene masks written like train.py:182-205."""
+    import json
+    from fabric_amd import train as T
+    root = str(tmp_path) + '/data/'
+    bands = ['B01', 'B02', 'B03', 'B04', 'B05', 'B06', 'B07', 'B08', 'B8A', 'B09', 'B10', 'B11', 'B12']
+    cities = {'aa': (128, 160), 'bb': (96, 96), 'cc': (100, 130)}
+    _synthetic_oscd(root, cities, bands, seed=8)
+    meta = {'band_ids': bands, 'band_means': {b: 3000.0 for b in bands}, 'band_stds': {b: 1500.0 for b in bands},
+            'patch_size': 32, 'stride': 32, 'batch_size': 8, 'validation_cities': ['cc'], 'epochs': 1}
+    mpath = str(tmp_path / 'metadata.json')
+    json.dump(meta, open(mpath, 'w'))
+    T.main(['--metadata', mpath, '--dataset_dir', root, '--log_dir', str(tmp_path / 'log'), '--augmentation', 'false'])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out['epoch'] == 0 and np.isfinite(out['train_cd_losses']) and 0 <= out['validate_cd_corrects'] <= 100
+    mask = ing.read_png_gray(str(tmp_path / 'log' / 'cc_epoch_0.png'))
+    assert mask.shape == cities['cc'] and set(np.unique(mask)) <= {0, 255}
