@@ -1,89 +1,71 @@
-"""Sub-parts of the U-Net: same class names, constructor signatures and sub-module
-tree as the reference's models/unet_parts.py:8-90, so ``state_dict()`` keys match
-key for key and pickled reference checkpoints resolve their class paths.
+"""Parameter containers of the U-Net stages.
 
-The modules own the parameters and BatchNorm buffers (plain torch.nn containers);
-the arithmetic is NOT torch's: BiDateNet.forward hands the whole graph to the HIP
-engine (fabric_amd/engine.py), where these stages exist as fused kernels
-(conv3x3 + BN statistics; BN+ReLU / max-pool / bilinear-upsample / concat folded
-into the consumer's loads).  Calling a part on its own therefore goes through the
-same engine via ``run_part`` and requires a ROCm device.
+Class names, constructor signatures and the sub-module tree are those of the reference's models/unet_parts.py:8-90
+-- that is what makes ``state_dict()`` keys match key for key (``conv.conv.0.weight`` ...) and lets pickled
+reference checkpoints resolve their class paths.  Nothing else is shared with it: the modules only OWN parameters and
+BatchNorm buffers.  The arithmetic is not torch's -- BiDateNet.forward hands the whole graph to the HIP engine
+(fabric_amd/engine.py), where these stages exist as fused kernels (conv3x3 + BN statistics; BN+ReLU / max-pool /
+bilinear-upsample / concat folded into the consumer's loads) -- so a part cannot be called on its own.
 """
-import torch
 import torch.nn as nn
 
 
-class double_conv(nn.Module):
-    '''(conv => BN => ReLU) * 2   -- reference models/unet_parts.py:8-23'''
+class _Part(nn.Module):
+    """A stage that exists only inside BiDateNet's fused schedule."""
+
+    def forward(self, *inputs):
+        raise RuntimeError(
+            f'fabric_amd: {type(self).__name__} is a parameter container; the U-Net parts run only as fused HIP stages '
+            f'inside BiDateNet.forward (conv3x3+BN statistics, BN+ReLU on load, fused pool / upsample / concat)')
+
+
+def _two_conv_bn_relu(in_ch, out_ch):
+    """[Conv3x3, BN, ReLU] x 2 as one Sequential: indices 0,1 / 3,4 hold the parameters (reference unet_parts.py:13-18)."""
+    stages = []
+    for c_in in (in_ch, out_ch):
+        stages += [nn.Conv2d(c_in, out_ch, kernel_size=3, padding=1), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True)]
+    return nn.Sequential(*stages)
+
+
+class double_conv(_Part):
+    """reference models/unet_parts.py:8-23"""
 
     def __init__(self, in_ch, out_ch):
-        super(double_conv, self).__init__()
-        self.conv = nn.Sequential(
-            nn.Conv2d(in_ch, out_ch, 3, padding=1),
-            nn.BatchNorm2d(out_ch),
-            nn.ReLU(inplace=True),
-            nn.Conv2d(out_ch, out_ch, 3, padding=1),
-            nn.BatchNorm2d(out_ch),
-            nn.ReLU(inplace=True)
-        )
-
-    def forward(self, x):
-        _no_standalone(self)
+        super().__init__()
+        self.conv = _two_conv_bn_relu(in_ch, out_ch)
 
 
-class inconv(nn.Module):
-    '''reference models/unet_parts.py:26-33'''
+class inconv(_Part):
+    """reference models/unet_parts.py:26-33"""
 
     def __init__(self, in_ch, out_ch):
-        super(inconv, self).__init__()
+        super().__init__()
         self.conv = double_conv(in_ch, out_ch)
 
-    def forward(self, x):
-        _no_standalone(self)
 
-
-class down(nn.Module):
-    '''MaxPool2d(2) => double_conv -- reference models/unet_parts.py:36-46'''
+class down(_Part):
+    """pool, then double_conv: the pool sits at index 0 so the parameters live under ``mpconv.1`` (unet_parts.py:36-46)"""
 
     def __init__(self, in_ch, out_ch):
-        super(down, self).__init__()
-        self.mpconv = nn.Sequential(
-            nn.MaxPool2d(2),
-            double_conv(in_ch, out_ch)
-        )
-
-    def forward(self, x):
-        _no_standalone(self)
+        super().__init__()
+        self.mpconv = nn.Sequential(nn.MaxPool2d(2), double_conv(in_ch, out_ch))
 
 
-class up(nn.Module):
-    '''bilinear x2 (align_corners) => pad => cat([skip, up]) => double_conv
-    -- reference models/unet_parts.py:49-80'''
+class up(_Part):
+    """bilinear x2 (align_corners) -> pad -> cat([skip, up]) -> double_conv (unet_parts.py:49-80).  Only the bilinear
+    variant exists: BiDateNet never takes the reference's ConvTranspose2d branch (unet_parts.py:59-60)."""
 
     def __init__(self, in_ch, out_ch, bilinear=True):
-        super(up, self).__init__()
+        super().__init__()
         if not bilinear:
-            # the reference's ConvTranspose2d branch (unet_parts.py:59-60) is never taken by BiDateNet
             raise NotImplementedError('fabric_amd: only the bilinear up path (the one BiDateNet uses) is built')
-        self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)    # parameter-free; kept for the module tree
         self.conv = double_conv(in_ch, out_ch)
 
-    def forward(self, x1, x2):
-        _no_standalone(self)
 
-
-class outconv(nn.Module):
-    '''1x1 classifier -- reference models/unet_parts.py:83-90'''
+class outconv(_Part):
+    """1x1 classifier (unet_parts.py:83-90)"""
 
     def __init__(self, in_ch, out_ch):
-        super(outconv, self).__init__()
-        self.conv = nn.Conv2d(in_ch, out_ch, 1)
-
-    def forward(self, x):
-        _no_standalone(self)
-
-
-def _no_standalone(mod):
-    raise RuntimeError(
-        f'fabric_amd: {type(mod).__name__} is executed as fused HIP stages inside BiDateNet.forward; '
-        f'it has no stand-alone (and no CPU / eager-PyTorch) path. Call the parent BiDateNet.')
+        super().__init__()
+        self.conv = nn.Conv2d(in_ch, out_ch, kernel_size=1)
