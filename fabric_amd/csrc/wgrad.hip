@@ -677,6 +677,216 @@ static int launch_wgrad3(const WgradArgs& a, hipStream_t st) {
     return BDN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad5: wgrad2 split by ROLE.  Per-row cycle stamps of wgrad2 (s_memtime around every patch row) show where its chunk
+// goes: a row of nine MFMAs is 288 cycles of matrix core, but the row that also issues the ten global loads takes 1250,
+// a row with two BatchNorm'd LDS stores 600, with two plain stores 430 -- a wave cannot issue MFMAs while it sits in a
+// vector-memory / LDS-write / VALU instruction, and with one wave per SIMD nobody else can either.  Here a block is
+// eight waves: waves 0-3 (one per SIMD) are CONSUMERS -- fragment reads and MFMAs only, wgrad2's row walk, 72 MFMAs per
+// chunk -- and waves 4-7 are PRODUCERS that own the whole staging of the next chunk (global loads two chunks ahead,
+// BatchNorm + ReLU, masks, LDS writes).  Same 64 x 64 x 9 tile, same 80 KB double buffer, same one barrier per chunk,
+// same partial-sum traffic; the consumer's accumulators and the producer's prefetch sets live in different waves, so
+// both fit the 256 registers that two waves per SIMD allow.
+template <bool USE_BN>
+__global__ __launch_bounds__(512, 1) void wgrad5_kernel(WgradArgs a) {
+    constexpr int PW = Wg2::PW, STR = Wg2::STR, BUF = Wg2::BUF, PATCH_BYTES = Wg2::PATCH_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.n_cot * a.n_cit;
+    const int tile = logical % ntile, split = logical / ntile;
+    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
+    const int Cin = a.C0 + a.C1;
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    unsigned char* buf0 = smem;
+    unsigned char* buf1 = smem + BUF;
+    if (q_begin >= q_end) return;                              // (never: the plan leaves no empty split) -- uniform for the block
+
+    if (wave >= 4) {
+        // ================================================= producer: stage chunk q+1 while the consumers are in chunk q
+        const int tid = threadIdx.x & 255;
+        const bf16s* src; int Csrc, cs;
+        if (ci0 < a.C0) { src = reinterpret_cast<const bf16s*>(a.in0); Csrc = a.C0; cs = ci0; }
+        else { src = reinterpret_cast<const bf16s*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
+        const bf16s* dzp = reinterpret_cast<const bf16s*>(a.dz);
+        const int u_pix = tid >> 3, sub = tid & 7, sub_e = sub * 8;
+        const unsigned wbase = u_pix * STR + ((sub ^ (((u_pix >> 1) & 1) << 2)) * 16);
+        int pyx[6];
+        unsigned poff[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
+            pyx[i] = pix < Wg2::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (int)0xf0000000;   // never inside
+            poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub_e) * 2);
+        }
+        const int dpx = u_pix & 15, dpy0 = u_pix >> 4;
+        const unsigned poff_c = (unsigned)((((a.W + 1)) * Csrc + cs + sub_e) * 2);
+        const unsigned drow = (unsigned)(a.W * a.Cout * 2);
+        const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + sub_e) * 2);
+        const unsigned doff_c = (unsigned)((co0 + sub_e) * 2);
+        uint4 pA[6], dA[4], pB[6], dB[4];
+        unsigned mA = 0, mB = 0;
+        int gA = 0, gB = 0;
+        int cur_grp = -1;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
+        int lq = q_begin;
+        int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
+        int lg = ln / a.imgs_per_group;
+        int lpix = 0;
+#define WG_LOAD(P, D, M, G)                                                                              \
+        {                                                                                               \
+            const bool live_ = lq < q_end;                                                              \
+            const int y0_ = lty * 8, x0_ = ltx * 16;                                                    \
+            const int pixbase_ = live_ ? (ln * a.H + y0_) * a.W + x0_ : lpix;                           \
+            lpix = pixbase_;                                                                            \
+            const unsigned char* sp_ = reinterpret_cast<const unsigned char*>(src) + ((long)(pixbase_ - a.W - 1) * Csrc) * 2; \
+            const unsigned char* dp_ = reinterpret_cast<const unsigned char*>(dzp) + ((long)pixbase_ * a.Cout) * 2; \
+            if (live_) G = lg;                                                                          \
+            unsigned m_ = 0;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
+                const int y_ = y0_ + (pyx[i] >> 16), x_ = x0_ + (short)(pyx[i] & 0xffff);               \
+                const bool ok_ = live_ && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W; \
+                P[i] = *reinterpret_cast<const uint4*>(sp_ + (ok_ ? poff[i] : poff_c));                 \
+                m_ |= (ok_ ? 1u : 0u) << i;                                                             \
+            }                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                              \
+                const bool ok_ = live_ && (y0_ + dpy0 + 2 * i) < a.H && (x0_ + dpx) < a.W;              \
+                D[i] = *reinterpret_cast<const uint4*>(dp_ + (ok_ ? doff0 + (unsigned)(2 * i) * drow : doff_c)); \
+                m_ |= (ok_ ? 1u : 0u) << (8 + i);                                                       \
+            }                                                                                           \
+            M = m_;                                                                                     \
+            if (live_) {                                                                                \
+                lq++;                                                                                   \
+                if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
+            }                                                                                           \
+        }
+#define WG_GROUP(g_)                                                                                     \
+        if (USE_BN && (g_) != cur_grp) {                                                                \
+            cur_grp = (g_);                                                                             \
+            const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub_e;                          \
+            const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub_e;                          \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }            \
+        }
+#define WG_STAGE(P, D, M, G, wb_)                                                                        \
+        {                                                                                               \
+            WG_GROUP(G)                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
+                uint4 v_ = P[i];                                                                        \
+                if (USE_BN) v_ = bnrelu_unit<bf16s>(v_, sc, sh);                                        \
+                const bool ok_ = ((M) >> i) & 1u;                                                       \
+                v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+                *reinterpret_cast<uint4*>((wb_) + wbase + i * 32 * STR) = v_;                           \
+            }                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                              \
+                uint4 v_ = D[i];                                                                        \
+                const bool ok_ = ((M) >> (8 + i)) & 1u;                                                 \
+                v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+                *reinterpret_cast<uint4*>((wb_) + PATCH_BYTES + wbase + i * 32 * STR) = v_;             \
+            }                                                                                           \
+        }
+        WG_LOAD(pA, dA, mA, gA)
+        WG_LOAD(pB, dB, mB, gB)
+        WG_STAGE(pA, dA, mA, gA, buf0)
+        WG_LOAD(pA, dA, mA, gA)
+        __syncthreads();
+        for (int q = q_begin; q < q_end; q += 2) {
+            WG_STAGE(pB, dB, mB, gB, buf1)
+            WG_LOAD(pB, dB, mB, gB)
+            __syncthreads();
+            WG_STAGE(pA, dA, mA, gA, buf0)                    // an odd tail stages an all-zero chunk (masks are clear past q_end)
+            WG_LOAD(pA, dA, mA, gA)
+            __syncthreads();
+        }
+#undef WG_LOAD
+#undef WG_GROUP
+#undef WG_STAGE
+        return;
+    }
+
+    // ===================================================== consumer: wgrad2's row walk, fragment reads and MFMAs only
+    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int kpix = (lane & 15) >> 2;
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;
+    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
+    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
+    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
+#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
+    uint4 af[4], bq[2][3];
+#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
+#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
+#define WG_ROW(pr_)                                                                                      \
+    {                                                                                                   \
+        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
+        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) } \
+        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
+        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) } \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+#define WG_CHUNK(rb_)                                                                                    \
+    {                                                                                                   \
+        const unsigned char* rb = (rb_);                                                                \
+        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)                        \
+        WG_ROW(0) WG_ROW(1) WG_ROW(2) WG_ROW(3) WG_ROW(4) WG_ROW(5) WG_ROW(6) WG_ROW(7) WG_ROW(8) WG_ROW(9) \
+    }
+    __syncthreads();
+    for (int q = q_begin; q < q_end; q += 2) {
+        WG_CHUNK(buf0)
+        __syncthreads();
+        WG_CHUNK(buf1)
+        __syncthreads();
+    }
+#undef TRP
+#undef LDA
+#undef LDB
+#undef B_BASE
+#undef WG_MMA
+#undef WG_ROW
+#undef WG_CHUNK
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
+        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;                 // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
+        }
+    }
+}
+
+template <bool USE_BN>
+static int launch_wgrad5(const WgradArgs& a, hipStream_t st) {
+    auto kern = wgrad5_kernel<USE_BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2::SMEM);
+        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad5: hipFuncSetAttribute(%d): %s", Wg2::SMEM, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(512), Wg2::SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad5");
+    return BDN_OK;
+}
+
 // dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
 // Block = SL split lanes x (256/SL) (co,ci) pairs: reads are coalesced along ci, the SL lanes walk the
 // splits in parallel (fixed order -> deterministic), an LDS tree combines them, and each pair's nine taps
@@ -733,7 +943,10 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 #define WG_SIMPLE_MULT 2
 #endif
 static int g_wgrad_blocks = 256;      // bdn_set_tuning(BDN_TUNE_WGRAD_BLOCKS): target grid size of the weight-gradient GEMM
-static int g_wgrad_v3 = 0;           // bdn_set_tuning(BDN_TUNE_WGRAD_V3): 1 = eight-wave kernel where the shape allows it.  Off by default:
+static int g_wgrad_v3 = 0;           // bdn_set_tuning(BDN_TUNE_WGRAD_V3): 1 = eight-wave 128x64 kernel (wgrad3) where the shape allows it; 2 = the
+                                     // producer / consumer kernel (wgrad5) wherever wgrad2 would run.  Both are off by default: each is faster
+                                     // alone (wgrad5: -16..20 % on the layers without BatchNorm-on-load, bit-identical results) but fills the
+                                     // CU's register file, so the dz -> dgrad chain's kernels no longer run beside it (step +3 %).  wgrad3:
                                      // -4 % on the weight gradients alone, but half the tiles means twice the splits and twice the partial-tile
                                      // traffic, and the training step gets 1.9 % SLOWER (tools/ab_wgblocks.py 0,1 2)
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; bool v3; };
@@ -742,7 +955,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
     p.g = pick_tile(N, H, W, imgs_per_group);
     // eight-wave 128x64-tile kernel: where the shape allows it and every block still gets at least 16 chunks (with
     // fewer, the wider tile's prologue / epilogue outweighs its cheaper staging: d1b, d2b stay on wgrad2)
-    p.v3 = g_wgrad_v3 && Cout % 128 == 0 && Cin > 32 && Cin % 64 == 0 && p.g.TI == 1;
+    p.v3 = g_wgrad_v3 == 1 && Cout % 128 == 0 && Cin > 32 && Cin % 64 == 0 && p.g.TI == 1;
     if (p.v3) {
         const int t3 = (Cout / 128) * ((Cin + 63) / 64);
         int s3 = (g_wgrad_blocks + t3 - 1) / t3;
@@ -767,7 +980,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_gr
 
 extern "C" int bdn_set_tuning(int key, int value) {
     if (key == BDN_TUNE_WGRAD_BLOCKS && value >= 1 && value <= 4096) { g_wgrad_blocks = value; return BDN_OK; }
-    if (key == BDN_TUNE_WGRAD_V3 && (value == 0 || value == 1)) { g_wgrad_v3 = value; return BDN_OK; }
+    if (key == BDN_TUNE_WGRAD_V3 && value >= 0 && value <= 2) { g_wgrad_v3 = value; return BDN_OK; }
     BDN_FAIL(BDN_E_ARG, "set_tuning: unknown key %d or value %d out of range", key, value);
 }
 
@@ -831,6 +1044,7 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
         const bool use_v2 = v2;
 #endif
         if (use_v2 && p.v3 && C0 % 64 == 0) rc = a.in_bn ? launch_wgrad3<true>(a, st) : launch_wgrad3<false>(a, st);
+        else if (use_v2 && g_wgrad_v3 == 2) rc = a.in_bn ? launch_wgrad5<true>(a, st) : launch_wgrad5<false>(a, st);
         else if (use_v2) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
         else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);

@@ -54,8 +54,9 @@ int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stre
  * BDN_TUNE_WGRAD_BLOCKS: target number of blocks of the weight-gradient GEMM (default 256 = one per CU); changes
  * bdn_wgrad_workspace_bytes, so set it before sizing workspaces. */
 #define BDN_TUNE_WGRAD_BLOCKS 1
-#define BDN_TUNE_WGRAD_V3 2       /* 1: eight-wave 128x64-tile weight-gradient kernel where the shape allows (faster alone,
-                                      slower inside the overlapped training step; default 0) */
+#define BDN_TUNE_WGRAD_V3 2       /* 1: eight-wave 128x64-tile weight-gradient kernel where the shape allows; 2: producer / consumer
+                                      kernel (four MFMA waves + four staging waves, results bit-identical to the default).  Both are
+                                      faster alone and slower inside the overlapped training step; default 0 */
 int bdn_set_tuning(int key, int value);
 
 /* ---- 3x3 convolution, stride 1, zero padding 1: nn.Conv2d(ci,co,3,padding=1), models/unet_parts.py:13,16 ----

@@ -576,3 +576,36 @@ def test_wgrad3_eight_wave_variant_matches_wgrad2():
         _lib.call('bdn_set_tuning', 2, 0)
     assert torch.isfinite(out[1]).all()
     assert_close('wgrad3 vs wgrad2', out[1], out[0], 2e-6)
+
+
+@pytest.mark.parametrize('mode', ['bnrelu', 'plain2'])
+def test_wgrad5_producer_consumer_variant_is_bit_identical_to_wgrad2(mode):
+    """BDN_TUNE_WGRAD_V3 = 2: the role-split kernel (waves 0-3 MFMA, waves 4-7 staging) keeps wgrad2's tile, split plan and
+    accumulation order, so its result is the same float for float (ragged map, two statistic groups / two concatenated sources)."""
+    lib = _lib.load()
+    N, H, W, Cout, ipg = 6, 37, 50, 128, 3
+    dt, td = DT['bf16']
+    dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 195)))
+    if mode == 'bnrelu':
+        C0, C1 = 128, 0
+        x0, x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 196))), None
+        bn_d, in_mode = dev(bn_table(N // ipg, C0, 197)), IN_BNRELU
+    else:
+        C0, C1 = 64, 64
+        x0 = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 196)))
+        x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C1, H, W), 198)))
+        bn_d, in_mode = None, 0
+    out = {}
+    try:
+        for v in (0, 2):
+            _lib.call('bdn_set_tuning', 2, v)
+            part = torch.empty(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0 + C1, ipg) // 4, device='cuda')
+            dw = torch.full((Cout, C0 + C1, 3, 3), float('nan'), device='cuda')
+            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x0.data_ptr(), C0, x1.data_ptr() if x1 is not None else None, C1,
+                      in_mode, bn_d.data_ptr() if bn_d is not None else None, ipg, part.data_ptr(), dw.data_ptr(), C0 + C1, N, H, W, st())
+            torch.cuda.synchronize()
+            out[v] = dw.cpu()
+    finally:
+        _lib.call('bdn_set_tuning', 2, 0)
+    assert torch.isfinite(out[2]).all()
+    assert torch.equal(out[2], out[0])

@@ -1,10 +1,11 @@
-// How many independent VALU / LDS-read / SALU instructions issue in the shadow of one 32x32x16 bf16 MFMA (1 wave per SIMD)?
+// How many independent VALU / LDS-read / SALU instructions issue in the shadow of one 32x32x16 bf16 MFMA -- with one wave per SIMD
+// (256 threads) and with two (512 threads)?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <int K, int MODE>
-__global__ void __launch_bounds__(256, 1) k(float* out, int iters) {
+__global__ void __launch_bounds__(512, 1) k(float* out, int iters) {
     __shared__ float lds[4096];
     f32x16 acc[4];
     for (int t = 0; t < 4; t++) for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
@@ -46,24 +47,28 @@ __global__ void __launch_bounds__(256, 1) k(float* out, int iters) {
     }
     float r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
     for (int t = 0; t < 4; t++) r += acc[t][0];
-    out[blockIdx.x * 256 + threadIdx.x] = r;
+    out[blockIdx.x * 512 + threadIdx.x] = r;
 }
-template <int K, int MODE> void run(float* out, const char* what) {
+template <int K, int MODE> void run(float* out, const char* what, int threads = 256) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    hipLaunchKernelGGL((k<K, MODE>), dim3(256), dim3(256), 0, 0, out, 100);
+    hipLaunchKernelGGL((k<K, MODE>), dim3(256), dim3(threads), 0, 0, out, 100);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<K, MODE>), dim3(256), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL((k<K, MODE>), dim3(256), dim3(threads), 0, 0, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    double per = ms * 1e-3 / (iters * 4.0);
-    printf("%s K=%2d : %.1f ns per MFMA (+K)  = %.1f cycles @2.4GHz\n", what, K, per * 1e9, per * 2.4e9);
+    double per = ms * 1e-3 / (iters * 4.0 * (threads / 256));
+    printf("[%d thr] %s K=%2d : %.1f ns per MFMA (+K)  = %.1f cycles @2.4GHz\n", threads, what, K, per * 1e9, per * 2.4e9);
 }
 int main() {
-    float* out; hipMalloc(&out, 256 * 256 * 4);
+    float* out; hipMalloc(&out, 256 * 512 * 4);
     run<0, 0>(out, "valu"); run<2, 0>(out, "valu"); run<4, 0>(out, "valu"); run<6, 0>(out, "valu"); run<7, 0>(out, "valu");
     run<8, 0>(out, "valu"); run<10, 0>(out, "valu"); run<12, 0>(out, "valu");
     run<1, 1>(out, "lds "); run<2, 1>(out, "lds "); run<4, 1>(out, "lds ");
     run<4, 2>(out, "salu"); run<8, 2>(out, "salu"); run<16, 2>(out, "salu");
+    printf("-- two waves per SIMD (time per MFMA per SIMD)\n");
+    run<0, 0>(out, "valu", 512); run<4, 0>(out, "valu", 512); run<8, 0>(out, "valu", 512); run<12, 0>(out, "valu", 512);
+    run<2, 1>(out, "lds ", 512); run<4, 1>(out, "lds ", 512);
+    run<8, 2>(out, "salu", 512); run<16, 2>(out, "salu", 512);
     return 0;
 }
