@@ -27,6 +27,8 @@ SIGNATURES = {
     'bdn_conv3x3_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_wgrad_ex': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_wgrad_variant': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    'bdn_conv3x3_wgrad_bnbwd_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    'bdn_conv3x3_wgrad_bnbwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_finalize_workspace_bytes': (_sz, [_i, _i, _i]),
     'bdn_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),
+    'bdn_bn_bwd_finalize': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_bwd_apply': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_overlap_loss': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_focal_workspace_bytes': (_sz, []),

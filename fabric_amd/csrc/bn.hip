@@ -443,6 +443,17 @@ extern "C" int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* 
     BDN_FAIL(BDN_E_ARG, "bn_bwd_apply: bad dtype");
 }
 
+// The finalize step alone (partial rows -> sums / dgamma / dbeta): for a consumer that applies the backward itself
+// (bdn_conv3x3_wgrad_bnbwd).
+extern "C" int bdn_bn_bwd_finalize(const float* bn, int G, int C, const float* partial, int rows_per_group, int raw_moment,
+                                   float* sums, float* dgamma, float* dbeta, void* scratch, void* stream) {
+    if (!bn || !partial || !sums) BDN_FAIL(BDN_E_ARG, "bn_bwd_finalize: null pointer");
+    if (G <= 0 || C <= 0 || C % 16 || C > 1024 || 1024 % C || rows_per_group <= 0) BDN_FAIL(BDN_E_SHAPE, "bn_bwd_finalize: bad shape");
+    launch_bn_bwd_finalize(partial, rows_per_group, G, C, sums, dgamma, dbeta, raw_moment ? bn : (const float*)nullptr, scratch, (hipStream_t)stream);
+    BDN_CHECK_LAUNCH("bn_bwd_finalize");
+    return BDN_OK;
+}
+
 extern "C" int bdn_bn_bwd(int dtype, const void* dA, int ldA, const void* z, const float* bn,
                           int imgs_per_group, int N, int H, int W, int C,
                           float* ws, float* sums, float* dgamma, float* dbeta, void* dz, void* stream) {

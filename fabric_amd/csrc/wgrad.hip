@@ -887,6 +887,183 @@ static int launch_wgrad5(const WgradArgs& a, hipStream_t st) {
     return BDN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad_first: the FIRST layer's weight gradient with its BatchNorm+ReLU backward fused in.  The first conv has no data
+// gradient, so its dz (the largest tensor of the step, 2B x 128 x 128 x 64) has exactly one reader: this GEMM.  Writing it
+// with bn_bwd_apply and reading it back is a 0.8 GB round trip at the very end of the step, where nothing of the dz chain
+// is left to overlap it.  Here the staging loads dA and z instead, applies bn_bwd_apply's formula (same expression, so the
+// bf16 dz values -- and the result -- are the same as the two-kernel path's) and writes the rounded dz straight into the
+// LDS operand tile.  Shape class: bf16, Cin_pad = 16, Cout = 64, 8x16 tiles.  With 16 input channels a 32-wide MFMA column
+// block holds TWO taps (lanes' columns 0-15 read tap 2j, columns 16-31 tap 2j+1 of the same 16-channel patch row), so a
+// k-step is 5 MFMAs instead of 9 and a wave carries 80 accumulator registers.  Two waves per co half split the k-steps of a
+// chunk and are added through LDS at the end; two or three blocks share a CU, which is what hides the staging here.
+struct WgFirstArgs {
+    const bf16s* dA; int ldA; const bf16s* z; const float* bn; const float* sums; const bf16s* x;
+    float* partial;                // [S][9][64][16]
+    int N, H, W, imgs_per_group;
+    int tiles_y, tiles_x, n_mtiles, S, per_split;
+    float invM;
+};
+struct WgF {
+    using TL = Tile<8, 16, 1>;
+    static constexpr int PSTR = 32;                            // 16 bf16 channels per patch pixel
+    static constexpr int PATCH_BYTES = TL::NPIX * PSTR;        // 5760
+    static constexpr int DSTR = 192;                           // dz pixel stride (128 B + 64: conflict-free transposing reads)
+    static constexpr int DZ_BYTES = TL::BM * DSTR;             // 24576
+    static constexpr int RED_BYTES = 2 * 5 * 16 * 64 * 4;      // the two odd-k waves' accumulators
+    static constexpr int SMEM = (PATCH_BYTES + DZ_BYTES) > RED_BYTES ? (PATCH_BYTES + DZ_BYTES) : RED_BYTES;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_first_kernel(WgFirstArgs a) {
+    using TL = WgF::TL;
+    constexpr int C = 64, PSTR = WgF::PSTR, DSTR = WgF::DSTR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch = smem;
+    unsigned char* dzt = smem + WgF::PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, kpar = wave & 1;                // co [wm*32,+32); k-steps kpar, kpar+2, ...
+    const int half = lane >> 5, l31 = lane & 31;
+    const int split = xcd_remap(blockIdx.x, gridDim.x);
+
+    // staging ownership: dz units u = tid + 256 i -> (tile slot u >> 3, channels 8 (tid & 7) ..); patch units
+    // u = tid + 256 i < 360 -> (patch pixel u >> 1, channels 8 (u & 1) ..)
+    const int c8 = (tid & 7) * 8;
+    uint4 gq[4], zq[4], pq[2];
+    unsigned ok = 0;                                           // bits 0-3: dz unit inside the image; bits 8-9: patch unit
+    int grp_next = 0, grp_cur = -1;
+    float mean[8], inv[8], sc[8], sh[8], k0[8], k1[8];
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+#define LOAD_CHUNK(q_)                                                                                   \
+    {                                                                                                   \
+        const int tx_ = (q_) % a.tiles_x, ty_ = ((q_) / a.tiles_x) % a.tiles_y, n_ = (q_) / (a.tiles_x * a.tiles_y); \
+        const int y0_ = ty_ * 8, x0_ = tx_ * 16;                                                        \
+        grp_next = n_ / a.imgs_per_group; ok = 0;                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
+            const int slot = (tid + i * 256) >> 3, y = y0_ + (slot >> 4), x = x0_ + (slot & 15);         \
+            const bool ok_ = y < a.H && x < a.W;                                                         \
+            const size_t pix = ((size_t)n_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);             \
+            gq[i] = *reinterpret_cast<const uint4*>(a.dA + pix * a.ldA + c8);                            \
+            zq[i] = *reinterpret_cast<const uint4*>(a.z + pix * C + c8);                                 \
+            ok |= (ok_ ? 1u : 0u) << i;                                                                  \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
+            const int u = tid + i * 256, pp = u >> 1, yy = pp / TL::PW, xx = pp % TL::PW;                \
+            const int y = y0_ + yy - 1, x = x0_ + xx - 1;                                                \
+            const bool ok_ = u < TL::NPIX * 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
+            const size_t pix = ((size_t)n_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);             \
+            pq[i] = *reinterpret_cast<const uint4*>(a.x + pix * 16 + (u & 1) * 8);                       \
+            ok |= (ok_ ? 1u : 0u) << (8 + i);                                                            \
+        }                                                                                               \
+    }
+#define STORE_CHUNK()                                                                                    \
+    {                                                                                                   \
+        if (grp_next != grp_cur) {                                                                      \
+            grp_cur = grp_next;                                                                         \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                              \
+                mean[e] = bn_row(a.bn, grp_cur, 0, C)[c8 + e]; inv[e] = bn_row(a.bn, grp_cur, 1, C)[c8 + e]; \
+                sc[e] = bn_row(a.bn, grp_cur, 2, C)[c8 + e]; sh[e] = bn_row(a.bn, grp_cur, 3, C)[c8 + e]; \
+                k0[e] = a.sums[((size_t)grp_cur * 2 + 0) * C + c8 + e] * a.invM;                         \
+                k1[e] = a.sums[((size_t)grp_cur * 2 + 1) * C + c8 + e] * a.invM;                         \
+            }                                                                                           \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
+            float fz[8], fg[8], o[8];                                                                   \
+            Unit<bf16s>::unpack(zq[i], fz);                                                              \
+            Unit<bf16s>::unpack(gq[i], fg);                                                              \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                              \
+                const float gm = fmaf(fz[e], sc[e], sh[e]) > 0.f ? fg[e] : 0.f;                          \
+                const float xhat = (fz[e] - mean[e]) * inv[e];                                          \
+                o[e] = sc[e] * (gm - k0[e] - xhat * k1[e]);                                             \
+            }                                                                                           \
+            uint4 v_ = Unit<bf16s>::pack(o);                                                             \
+            const bool ok_ = (ok >> i) & 1u;                                                             \
+            v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+            *reinterpret_cast<uint4*>(dzt + ((tid + i * 256) >> 3) * DSTR + (tid & 7) * 16) = v_;        \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
+            const int u = tid + i * 256;                                                                 \
+            uint4 v_ = pq[i];                                                                           \
+            const bool ok_ = (ok >> (8 + i)) & 1u;                                                       \
+            v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+            if (u < TL::NPIX * 2) *reinterpret_cast<uint4*>(patch + (u >> 1) * PSTR + (u & 1) * 16) = v_; \
+        }                                                                                               \
+    }
+
+    // MFMA operand addressing.  A (dz): pixel kpix of a 4-pixel group, 4-channel piece (lane & 3) of 16-channel block
+    // ((lane >> 4) & 1) of the wave's 32 co.  B (patch): the same pixel / piece roles over the 16 input channels; the lane's
+    // column block ((lane >> 4) & 1) selects the tap of the pair instead of a second 16-channel block.
+    const int kpix = (lane & 15) >> 2, upper = (lane >> 4) & 1;
+    const unsigned a_off = (half * 8 + kpix) * DSTR + wm * 64 + (16 * upper + 4 * (lane & 3)) * 2;
+    const unsigned b_off = (lane & 3) * 8;
+    unsigned tapoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int tap = min(2 * j + upper, 8);
+        tapoff[j] = ((tap / 3) * TL::PW + tap % 3) * PSTR + b_off;
+    }
+
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    if (q_begin < q_end) LOAD_CHUNK(q_begin)
+    for (int q = q_begin; q < q_end; q++) {
+        __syncthreads();                                   // previous chunk's LDS reads are done
+        STORE_CHUNK()
+        __syncthreads();
+        if (q + 1 < q_end) LOAD_CHUNK(q + 1)
+        __builtin_amdgcn_sched_barrier(0);                 // keep the prefetch loads above the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kk = 2 * ks + kpar;                  // 16-pixel k-step = tile row kk
+            const uint4 af = tr_pair(dzt + a_off + kk * 16 * DSTR, dzt + a_off + (kk * 16 + 4) * DSTR);
+            const unsigned char* pb = patch + (kk * TL::PW + half * 8 + kpix) * PSTR;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint4 bfr = tr_pair(pb + tapoff[j], pb + tapoff[j] + 4 * PSTR);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc[j], 0, 0, 0);
+            }
+        }
+    }
+#undef LOAD_CHUNK
+#undef STORE_CHUNK
+
+    // odd-k waves -> LDS -> even-k waves add and store partial[split][tap][co][ci]
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem) + (size_t)wm * 20 * 64 + lane;           // [wm][j][quad][lane]
+    if (kpar == 1) {
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                red[(j * 4 + qd) * 64] = make_float4(acc[j][4 * qd], acc[j][4 * qd + 1], acc[j][4 * qd + 2], acc[j][4 * qd + 3]);
+    }
+    __syncthreads();
+    if (kpar == 0) {
+        const int ci = l31 & 15;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int tap = 2 * j + (l31 >> 4);
+            float* pt = a.partial + (((size_t)split * 9 + tap) * C + wm * 32 + 4 * half) * 16 + ci;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const float4 o = red[(j * 4 + qd) * 64];
+                if (tap < 9) {
+                    pt[(8 * qd + 0) * 16] = acc[j][4 * qd + 0] + o.x;
+                    pt[(8 * qd + 1) * 16] = acc[j][4 * qd + 1] + o.y;
+                    pt[(8 * qd + 2) * 16] = acc[j][4 * qd + 2] + o.z;
+                    pt[(8 * qd + 3) * 16] = acc[j][4 * qd + 3] + o.w;
+                }
+            }
+        }
+    }
+}
+
 // dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
 // Block = SL split lanes x (256/SL) (co,ci) pairs: reads are coalesced along ci, the SL lanes walk the
 // splits in parallel (fixed order -> deterministic), an LDS tree combines them, and each pair's nine taps
@@ -1067,6 +1244,35 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
                                  int N, int H, int W, void* stream) {
     return bdn_conv3x3_wgrad_ex(dtype, dz, Cout, in0, C0, in1, C1, in_mode, in_bn, imgs_per_group, partial, dw_oihw, Cin_real,
                                 N, H, W, 3, stream);
+}
+
+// The first layer's weight gradient straight from dA and z (BatchNorm+ReLU backward applied while staging; `sums` from
+// bdn_bn_bwd_finalize).  Returns BDN_E_SHAPE outside its shape class -- ask bdn_conv3x3_wgrad_bnbwd_supported first.
+extern "C" int bdn_conv3x3_wgrad_bnbwd_supported(int dtype, int N, int H, int W, int Cout, int C0, int imgs_per_group) {
+    if (dtype != BDN_BF16 || Cout != 64 || C0 != 16 || N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group) return 0;
+    if (pick_tile(N, H, W, imgs_per_group).TI != 1) return 0;
+    return (size_t)N * H * W * 64 < ((size_t)1 << 31) ? 1 : 0;
+}
+
+extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const void* z, const float* bn, const float* sums,
+                                       int imgs_per_group, int Cout, const void* in0, int C0,
+                                       float* partial, float* dw_oihw, int Cin_real, int N, int H, int W, void* stream) {
+    if (!dA || !z || !bn || !sums || !in0 || !partial || !dw_oihw) BDN_FAIL(BDN_E_ARG, "wgrad_bnbwd: null pointer");
+    if (!bdn_conv3x3_wgrad_bnbwd_supported(dtype, N, H, W, Cout, C0, imgs_per_group))
+        BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: only bf16, Cout=64, C0=16, 8x16 tiles (got dtype %d Cout %d C0 %d)", dtype, Cout, C0);
+    if (ldA < 64 || ldA % 8 || Cin_real <= 0 || Cin_real > 16) BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: bad ldA=%d / Cin_real=%d", ldA, Cin_real);
+    const WgPlan p = wgrad_plan(N, H, W, Cout, C0, imgs_per_group);
+    WgFirstArgs a;
+    a.dA = (const bf16s*)dA; a.ldA = ldA; a.z = (const bf16s*)z; a.bn = bn; a.sums = sums; a.x = (const bf16s*)in0;
+    a.partial = partial; a.N = N; a.H = H; a.W = W; a.imgs_per_group = imgs_per_group;
+    a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles; a.S = p.S; a.per_split = p.per_split;
+    a.invM = 1.f / (float)((size_t)imgs_per_group * H * W);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(wgrad_first_kernel, dim3(p.S), dim3(256), WgF::SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad_first");
+    launch_wgrad_reduce(partial, dw_oihw, p.S, Cout, C0, Cin_real, st);
+    BDN_CHECK_LAUNCH("wgrad_reduce");
+    return BDN_OK;
 }
 
 // which kernel the GEMM phase runs (bench.py names its roofline line after it): 2 = wgrad2 pipeline, 1 = simple kernel

@@ -126,6 +126,8 @@ class Workspace:
         self.stats = f32(n_stats)
         self.bnws = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device=device)
         self.n_bnb, self.n_wg = n_bnb, n_wg
+        L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
+        self.n_wg1 = lib.bdn_wgrad_workspace_bytes(2 * B, H, W, L1.cout, L1.cin, B) // 4
         self._bwd = None
         self.logits = None
 
@@ -133,6 +135,7 @@ class Workspace:
         if self._bwd is None:
             self._bwd = dict(bnb=torch.empty(self.n_bnb, dtype=torch.float32, device=device),
                              wg=torch.empty(self.n_wg, dtype=torch.float32, device=device),
+                             wg1=torch.empty(self.n_wg1, dtype=torch.float32, device=device),
                              sums=torch.empty(2 * 2 * 1024, dtype=torch.float32, device=device))
         return self._bwd
 
@@ -159,6 +162,7 @@ class BiDateEngine:
         self._pack_desc = None
         self._packed_versions = None
         self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
+        self.fuse_first_wgrad = True    # A/B switch: the first conv's BatchNorm backward inside its weight-gradient GEMM (bf16 only)
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
         self._diag_skip_wgrad = False
         self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
@@ -497,6 +501,30 @@ class BiDateEngine:
             dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
             if late:
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
+            if k == 1 and rows and self.fuse_first_wgrad and \
+                    _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.dt, 2 * B, hk, wk, La.cout, La.cin, B):
+                # the first conv has no data gradient: its dz has one reader, so the BatchNorm backward is applied inside
+                # that weight-gradient GEMM's staging and the largest tensor of the step is never written (on the main
+                # stream: nothing of the chain is left to run, the side stream is still busy with e1b's GEMM)
+                call('bdn_bn_bwd_finalize', ptr(ws.bn[La.name]), 2, La.cout, ptr(ws.stats), rows, 1, ptr(sc['sums']),
+                     ptr(grads[f'{La.bn}.weight']), ptr(grads[f'{La.bn}.bias']), ptr(ws.bnws), st)
+                wargs = (self.dt, ptr(dAa), La.cout, ptr(ws.z[La.name]), ptr(ws.bn[La.name]), ptr(sc['sums']), B, La.cout,
+                         ptr(ws.x0), La.cin, ptr(sc['wg1']), ptr(grads[f'{La.conv}.weight']), La.cin_real, 2 * B, hk, wk, st)
+                if not self._diag_skip_wgrad:
+                    if self.prof is not None and self.prof_filter in (None, 'wgrad_first_kernel'):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        call('bdn_conv3x3_wgrad_bnbwd', *wargs)
+                        e1.record()
+                        self.prof.append(('wgrad_first_kernel', 2.0 * 2 * B * hk * wk * La.cout * 9 * La.cin, e0, e1))
+                    else:
+                        call('bdn_conv3x3_wgrad_bnbwd', *wargs)
+                if zero_bias_grads:
+                    grads[f'{La.conv}.bias'].zero_()
+                ready([f'{La.bn}.weight', f'{La.bn}.bias', f'{La.conv}.weight', f'{La.conv}.bias'])
+                keep += [dAb, dzb, dAa, dP]
+                dP = None
+                continue
             dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
             src = ws.x0 if k == 1 else ws.pool[k]
             if not late:

@@ -104,6 +104,16 @@ int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
                          float* partial, float* dw_oihw, int Cin_real,
                          int N, int H, int W, int phases, void* stream);
 int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group);
+/* Weight gradient of the FIRST convolution (inc.conv.conv.0, models/unet_parts.py:13 via unet_model.py inconv) with the
+ * BatchNorm+ReLU backward of its own output (unet_parts.py:14-15) fused into the staging: the layer has no data gradient,
+ * so dz = bn_bwd(dA, z) is never written -- the kernel reads dA [N,H,W,ldA>=64] and z [N,H,W,64], applies
+ * bdn_bn_bwd_apply's expression with `sums` from bdn_bn_bwd_finalize, rounds to bf16 and multiplies with the input patches
+ * in0 [N,H,W,16].  The result equals bdn_bn_bwd_apply + bdn_conv3x3_wgrad up to the summation order of the partial tiles.
+ * Shape class: bf16, Cout = 64, C0 = 16 (bdn_conv3x3_wgrad_bnbwd_supported); partial: bdn_wgrad_workspace_bytes(). */
+int bdn_conv3x3_wgrad_bnbwd_supported(int dtype, int N, int H, int W, int Cout, int C0, int imgs_per_group);
+int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const void* z, const float* bn, const float* sums,
+                            int imgs_per_group, int Cout, const void* in0, int C0,
+                            float* partial, float* dw_oihw, int Cin_real, int N, int H, int W, void* stream);
 
 /* ---- BatchNorm2d training statistics: nn.BatchNorm2d, models/unet_parts.py:14,17 ----
  * Reduces the conv's per-tile partials and produces, per group g and channel c,
@@ -140,6 +150,10 @@ int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const fl
                      int imgs_per_group, int N, int H, int W, int C,
                      const float* partial, int rows_per_group, int raw_moment,
                      float* sums, float* dgamma, float* dbeta, void* dz, void* scratch, void* stream);
+/* The reduction half of bdn_bn_bwd_apply alone: partial rows -> sums [G][2][C], dgamma, dbeta (same argument meaning),
+ * for a consumer that applies the backward while it stages dz (bdn_conv3x3_wgrad_bnbwd). */
+int bdn_bn_bwd_finalize(const float* bn, int G, int C, const float* partial, int rows_per_group, int raw_moment,
+                        float* sums, float* dgamma, float* dbeta, void* scratch, void* stream);
 
 /* ---- nn.MaxPool2d(2) on relu(bn(z)): models/unet_parts.py:40 (floor mode) ---- */
 int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_group,

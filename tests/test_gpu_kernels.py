@@ -502,6 +502,74 @@ def test_dgrad_with_fused_bn_bwd_stats(prec, case):
     assert_close('dz', dz.float().cpu(), dz_r.float().cpu(), 8e-3 if prec == 'bf16' else 2e-5)
 
 
+@pytest.mark.parametrize('case', [(4, 32, 32, 2, 64), (6, 37, 50, 3, 64), (2, 128, 128, 1, 64), (4, 24, 16, 2, 80)])
+def test_first_layer_wgrad_with_fused_bn_bwd(case):
+    """bdn_bn_bwd_finalize + bdn_conv3x3_wgrad_bnbwd == bdn_bn_bwd_apply + bdn_conv3x3_wgrad (bf16, 13 real channels padded to
+    16): same dgamma / dbeta / sums bit for bit, weight gradient equal up to the summation order of the partial tiles.
+    Ragged maps, several statistic groups, and a dA that is a 64-channel slice of a wider tensor (ldA = 80)."""
+    N, H, W, ipg, ldA = case
+    Cout, C0, Creal = 64, 16, 13
+    dt, td = DT['bf16']
+    G = N // ipg
+    lib = _lib.load()
+    assert lib.bdn_conv3x3_wgrad_bnbwd_supported(dt, N, H, W, Cout, C0, ipg) == 1
+    assert lib.bdn_conv3x3_wgrad_bnbwd_supported(dt, N, H, W, 128, C0, ipg) == 0
+    dA_full = to_nhwc('bf16', rnd('bf16', _rand((N, ldA, H, W), 301)))
+    z = rnd('bf16', _rand((N, Cout, H, W), 302))
+    z_d = to_nhwc('bf16', z)
+    x = rnd('bf16', _rand((N, C0, H, W), 303)); x[:, Creal:] = 0
+    x_d = to_nhwc('bf16', x)
+    bn = bn_table(G, Cout, 304)
+    for g in range(G):                                           # statistics of z itself so the ReLU masks are mixed
+        zg = z[g * ipg:(g + 1) * ipg].double()
+        mean, var = zg.mean((0, 2, 3)), zg.var((0, 2, 3), unbiased=False)
+        inv = 1 / torch.sqrt(var + 1e-5)
+        gamma = bn[g, 2].double() / bn[g, 1].double()
+        bn[g, 0], bn[g, 1] = mean.float(), inv.float()
+        bn[g, 2] = (gamma * inv).float()
+        bn[g, 3] = (0.1 - mean * gamma * inv).float()
+    bn_d = dev(bn)
+    # BatchNorm-backward partial sums the way the producers leave them: rows of (sum g, sum g*z)
+    y = torch.einsum('nchw,nc->nchw', z.float(), bn[:, 2].repeat_interleave(ipg, 0)) + bn[:, 3].repeat_interleave(ipg, 0)[:, :, None, None]
+    gm = torch.where(y > 0, dA_full.float().cpu().permute(0, 3, 1, 2)[:, :Cout], torch.zeros(()))
+    rows = 4
+    part = torch.zeros(G * rows, 2, Cout)
+    for g in range(G):
+        for r in range(rows):
+            sl = slice(g * ipg, (g + 1) * ipg)
+            hs = slice(r * H // rows, (r + 1) * H // rows)
+            part[g * rows + r, 0] = gm[sl, :, hs].double().sum((0, 2, 3)).float()
+            part[g * rows + r, 1] = (gm[sl, :, hs].double() * z[sl, :, hs].double()).sum((0, 2, 3)).float()
+    part_d = dev(part)
+    wsz = lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg) // 4
+    out = {}
+    for fused in (0, 1):
+        sums = torch.full((G, 2, Cout), float('nan'), device='cuda')
+        dg, db = torch.empty(Cout, device='cuda'), torch.empty(Cout, device='cuda')
+        wpart = torch.empty(wsz, device='cuda')
+        dw = torch.full((Cout, Creal, 3, 3), float('nan'), device='cuda')
+        if fused:
+            _lib.call('bdn_bn_bwd_finalize', bn_d.data_ptr(), G, Cout, part_d.data_ptr(), rows, 1, sums.data_ptr(), dg.data_ptr(),
+                      db.data_ptr(), None, st())
+            _lib.call('bdn_conv3x3_wgrad_bnbwd', dt, dA_full.data_ptr(), ldA, z_d.data_ptr(), bn_d.data_ptr(), sums.data_ptr(), ipg,
+                      Cout, x_d.data_ptr(), C0, wpart.data_ptr(), dw.data_ptr(), Creal, N, H, W, st())
+        else:
+            dz = torch.empty(N, H, W, Cout, dtype=td, device='cuda')
+            _lib.call('bdn_bn_bwd_apply', dt, dA_full.data_ptr(), ldA, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, Cout,
+                      part_d.data_ptr(), rows, 1, sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz.data_ptr(), None, st())
+            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x_d.data_ptr(), C0, None, 0, 0, None, ipg,
+                      wpart.data_ptr(), dw.data_ptr(), Creal, N, H, W, st())
+        torch.cuda.synchronize()
+        out[fused] = (sums.cpu(), dg.cpu(), db.cpu(), dw.cpu())
+    for i in range(3):
+        assert torch.equal(out[0][i], out[1][i])
+    assert torch.isfinite(out[1][3]).all()
+    assert_close('fused first-layer dW', out[1][3], out[0][3], 2e-6)
+    with pytest.raises(RuntimeError):
+        _lib.call('bdn_conv3x3_wgrad_bnbwd', dt, dA_full.data_ptr(), ldA, z_d.data_ptr(), bn_d.data_ptr(), sums.data_ptr(), ipg,
+                  128, x_d.data_ptr(), C0, wpart.data_ptr(), dw.data_ptr(), Creal, N, H, W, st())
+
+
 @pytest.mark.parametrize('prec', PRECS)
 @pytest.mark.parametrize('shape', [(2, 16, 16, 64), (1, 45, 22, 64), (2, 11, 11, 128), (1, 2, 3, 256)])
 def test_product_pool_equals_separate_kernels(prec, shape):

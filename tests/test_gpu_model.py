@@ -119,6 +119,30 @@ def test_train_step_matches_reference(golden_dir, name, prec):
     assert d2.max() <= (1e-3 if prec == 'fp32' else 0.25)
 
 
+@pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
+def test_first_layer_fused_weight_gradient_equals_two_kernel_path(golden_dir, name):
+    """engine.fuse_first_wgrad (bf16): BatchNorm backward applied inside the first conv's weight-gradient GEMM.  Every other
+    conv / BatchNorm gradient is produced by the same kernels (bit-equal); inc's conv weight differs only by summation order."""
+    g, c, x1, x2, lbl = _load(golden_dir, name)
+    grads = {}
+    for fused in (False, True):
+        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
+        model.engine().fuse_first_wgrad = fused
+        loss = _tversky_torch(model(x1, x2), lbl)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[fused] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        if k == 'inc.conv.conv.0.weight':
+            assert (a - b).abs().max() <= 2e-6 * b.abs().max(), k
+            assert not torch.equal(a, torch.zeros_like(a))
+        elif k.startswith('outc.'):                       # the 1x1 classifier's gradient is accumulated with float atomics
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max(), k
+        else:
+            assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90'])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_eval_mode_matches_reference(golden_dir, name, prec):
