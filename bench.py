@@ -84,10 +84,10 @@ def pmc_traffic(kernel, precision):
 
 def rocprof_avg_us(kernel, precision):
     """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
-    (profiles/r1_c_kernel_stats.csv), for comparison with the live event figure.  The event interval additionally
+    (profiles/r1_d_kernel_stats.csv), for comparison with the live event figure.  The event interval additionally
     contains the dispatch wait behind the side-stream weight-gradient blocks that hold the CUs when the kernel is
     enqueued (rocprofv3 counts a kernel from its first wave), so it is the larger of the two."""
-    path = os.path.join(ROOT, 'profiles', 'r1_c_kernel_stats.csv')
+    path = os.path.join(ROOT, 'profiles', 'r1_d_kernel_stats.csv')
     if precision != 'bf16' or not os.path.exists(path):
         return None
     import csv
