@@ -95,10 +95,90 @@ __global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ desc) {
     }
 }
 
+// Regular layers (bf16, Cin a multiple of 64 and unpadded, Cout of 32 -- 17 of BiDateNet's 18) go through LDS instead: a block
+// takes 32 output channels x 64 input channels x 9 taps, reads them as 32 contiguous 2304-byte rows of the OIHW master
+// (16-byte loads), and writes complete 1 KB fragment records of both images with 16-byte stores.  The element-wise kernel
+// above gathers 4-byte values 36 bytes apart and stores 2 bytes per lane: 61 us for the 107 MB of the step, and that
+// sits alone at the start of every step.
+__device__ __forceinline__ bool pack_regular(const PackDesc& d) { return d.Cin == d.Cinp && d.Cin % 64 == 0 && d.Cout % 32 == 0; }
+__global__ __launch_bounds__(256) void pack_weights_tiles_kernel(const PackDesc* __restrict__ desc, int n_layers) {
+    constexpr int ROW = 9 * 64 + 8;                            // LDS elements per output channel: [tap][ci] + 16 bytes of padding
+    __shared__ __attribute__((aligned(16))) bf16s t[32 * ROW];
+    const int tid = threadIdx.x;
+    for (int item = blockIdx.x;; item += gridDim.x) {
+        // which (layer, 32-co block, 64-ci block) is this item?
+        int l = 0, local = item;
+        for (; l < n_layers; l++) {
+            const int cnt = pack_regular(desc[l]) ? (desc[l].Cout / 32) * (desc[l].Cin / 64) : 0;
+            if (local < cnt) break;
+            local -= cnt;
+        }
+        if (l == n_layers) return;                             // uniform for the block
+        const PackDesc d = desc[l];
+        const int ncc = d.Cin / 64, cb = local / ncc, cc = local % ncc, co0 = cb * 32, ci0 = cc * 64;
+        __syncthreads();                                       // the previous item's LDS reads are done
+        for (int q = tid; q < 32 * 144; q += 256) {            // 144 float4 per output-channel row
+            const int r = q / 144, o4 = (q % 144) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(d.w + ((size_t)(co0 + r) * d.Cin + ci0) * 9 + o4);
+            const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int o = o4 + e, ci = o / 9, tap = o % 9;
+                t[r * ROW + tap * 64 + ci] = from_f<bf16s>(f[e]);
+            }
+        }
+        __syncthreads();
+        bf16s* wf = reinterpret_cast<bf16s*>(d.wf); bf16s* wd = reinterpret_cast<bf16s*>(d.wd);
+        for (int u = tid; u < 36 * 64; u += 256) {             // 36 records x 64 lanes, 16 bytes each
+            const int rec_l = u >> 6, lane = u & 63;
+            if (wf) {      // record (tap, kq): lane = co & 31 + 32 * (ci % 16) / 8, 8 consecutive ci
+                const int tap = rec_l >> 2, kq = rec_l & 3;
+                const size_t rec = ((size_t)cb * 9 + tap) * (d.Cin / 16) + (ci0 / 16 + kq);
+                *reinterpret_cast<uint4*>(wf + rec * 512 + lane * 8) =
+                    *reinterpret_cast<const uint4*>(t + (lane & 31) * ROW + tap * 64 + kq * 16 + (lane >> 5) * 8);
+            }
+            if (wd) {      // roles swapped, taps rotated: record (ci block, 8 - tap, co group of 16): 8 consecutive co
+                const int cbi = rec_l / 18, rem = rec_l % 18, tap = rem >> 1, kg = rem & 1;
+                const int ci = cbi * 32 + (lane & 31), co8 = kg * 16 + (lane >> 5) * 8;
+                unsigned short h[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) h[e] = t[(co8 + e) * ROW + tap * 64 + ci];
+                const size_t rec = ((size_t)(ci0 / 32 + cbi) * 9 + (8 - tap)) * (d.Cout / 16) + (co0 / 16 + kg);
+                *reinterpret_cast<uint4*>(wd + rec * 512 + lane * 8) =
+                    make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+            }
+        }
+    }
+}
+// the element-wise kernel restricted to the layers the tile kernel does not take
+__global__ void pack_weights_irregular_kernel(const PackDesc* __restrict__ desc) {
+    if (pack_regular(desc[blockIdx.y])) return;
+    constexpr int EPU = 8, KCH = 16, REC = 64 * EPU;
+    const PackDesc d = desc[blockIdx.y];
+    const size_t total = (size_t)d.Cout * 9 * d.Cinp;
+    bf16s* wf = reinterpret_cast<bf16s*>(d.wf); bf16s* wd = reinterpret_cast<bf16s*>(d.wd);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i % EPU, lane = (i / EPU) % 64; const size_t rec = i / REC;
+        if (wf) {
+            const int kgi = rec % (d.Cinp / KCH); const size_t t = rec / (d.Cinp / KCH); const int tap = t % 9, cb = t / 9;
+            const int co = cb * 32 + (lane & 31), ci = kgi * KCH + (lane >> 5) * EPU + e;
+            wf[i] = from_f<bf16s>(ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + tap] : 0.f);
+        }
+        if (wd) {
+            const int kgi = rec % (d.Cout / KCH); const size_t t = rec / (d.Cout / KCH); const int tap = t % 9, cb = t / 9;
+            const int ci = cb * 32 + (lane & 31), co = kgi * KCH + (lane >> 5) * EPU + e;
+            wd[i] = from_f<bf16s>(ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + (8 - tap)] : 0.f);
+        }
+    }
+}
+
 extern "C" int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stream) {
     if (!desc || n_layers <= 0) BDN_FAIL(BDN_E_ARG, "pack_weights_multi: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_weights_multi_kernel<bf16s>, dim3(256, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
+    if (dtype == BDN_BF16) {
+        hipLaunchKernelGGL(pack_weights_tiles_kernel, dim3(1024), dim3(256), 0, st, (const PackDesc*)desc, n_layers);
+        hipLaunchKernelGGL(pack_weights_irregular_kernel, dim3(32, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
+    }
     else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3(256, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
     else BDN_FAIL(BDN_E_ARG, "pack_weights_multi: bad dtype");
     BDN_CHECK_LAUNCH("pack_weights_multi");
@@ -257,8 +337,11 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
     if (!dlogits || !z || !bn || !w || !dA || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
     if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream; const int npix = B * H * W;
-    hipMemsetAsync(dw, 0, sizeof(float) * ncls * C, st);
-    hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
+    if (db == dw + (size_t)ncls * C) hipMemsetAsync(dw, 0, sizeof(float) * ncls * (C + 1), st);   // adjacent (flat gradient buffer): one fill
+    else {
+        hipMemsetAsync(dw, 0, sizeof(float) * ncls * C, st);
+        hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
+    }
     const unsigned grid = bdn_outc_bwd_rows(dtype, B, H, W, C);
     const size_t smem = sizeof(float) * (ncls * (C + 1) + (bs_partial ? 256 * (dtype == BDN_BF16 ? 8 : 4) * 2 : 0));
     if (dtype == BDN_BF16) {
@@ -404,8 +487,12 @@ extern "C" int bdn_overlap_loss(const float* logits, const uint8_t* labels, floa
     if (B <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int We = reduce_w ? 1 : W;
-    hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * We, st);
-    if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
+    if (counts && (const void*)counts == (const void*)(ws + (size_t)3 * ncls * We))           // counts right behind the sums: one fill
+        hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * We + sizeof(int32_t) * 4, st);
+    else {
+        hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * We, st);
+        if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
+    }
     int CW = 1; while (CW < W && CW < 256) CW *= 2;
     const int RL = 256 / CW, rows = B * H;
     int rpb = (rows + 255) / 256; if (rpb < RL) rpb = RL;                       // ~256 row blocks

@@ -502,6 +502,36 @@ def test_dgrad_with_fused_bn_bwd_stats(prec, case):
     assert_close('dz', dz.float().cpu(), dz_r.float().cpu(), 8e-3 if prec == 'bf16' else 2e-5)
 
 
+@pytest.mark.parametrize('prec', PRECS)
+def test_pack_weights_multi_equals_per_layer_pack(prec):
+    """bdn_pack_weights_multi (one call for a list of layers; bf16 takes the LDS-tiled kernel for regular layers and the
+    element-wise one for the rest) writes the same fragment-order images as bdn_pack_weights layer by layer."""
+    import struct
+    dt, td = DT[prec]
+    layers = [(64, 13, 16, False), (64, 64, 64, True), (128, 64, 64, True), (256, 384, 384, True), (64, 128, 128, True),
+              (96, 40, 48, True), (32, 64, 64, False)]                  # Cout, Cin, Cin_pad, with data-gradient image
+    ws, outs, rec = [], [], b''
+    for i, (co, ci, cip, has_wd) in enumerate(layers):
+        if has_wd and cip % 32:
+            continue
+        w = dev(_rand((co, ci, 3, 3), 400 + i))
+        wf = torch.full((co * 9 * cip,), 7.0, dtype=td, device='cuda')
+        wd = torch.full((co * 9 * cip,), 7.0, dtype=td, device='cuda') if has_wd else None
+        ws.append((w, co, ci, cip)); outs.append((wf, wd))
+        rec += struct.pack('<QQQiiii', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if has_wd else 0, co, ci, cip, 0)
+    desc = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+    _lib.call('bdn_pack_weights_multi', dt, desc.data_ptr(), len(ws), st())
+    torch.cuda.synchronize()
+    for (w, co, ci, cip), (wf, wd) in zip(ws, outs):
+        rf = torch.empty_like(wf)
+        rd = torch.empty_like(wd) if wd is not None else None
+        _lib.call('bdn_pack_weights', dt, w.data_ptr(), rf.data_ptr(), rd.data_ptr() if rd is not None else None, co, ci, cip, st())
+        torch.cuda.synchronize()
+        assert torch.equal(wf, rf), (co, ci)
+        if wd is not None:
+            assert torch.equal(wd, rd), (co, ci)
+
+
 @pytest.mark.parametrize('case', [(4, 32, 32, 2, 64), (6, 37, 50, 3, 64), (2, 128, 128, 1, 64), (4, 24, 16, 2, 80)])
 def test_first_layer_wgrad_with_fused_bn_bwd(case):
     """bdn_bn_bwd_finalize + bdn_conv3x3_wgrad_bnbwd == bdn_bn_bwd_apply + bdn_conv3x3_wgrad (bf16, 13 real channels padded to
