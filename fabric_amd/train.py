@@ -47,9 +47,11 @@ def train_epoch(step, loader, dev, patch_size):
     """train.py:73-118 without the per-step host round trip: losses / counts are read back once per epoch."""
     step.model.train()
     recs = []
-    for b1, b2, labels in loader:
-        loss = step.step(b1.to(dev, non_blocking=True), b2.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
-        recs.append((loss.clone(), step.last_counts.clone(), labels.shape[0]))
+    with torch.cuda.stream(step.stream()):                # the loop lives on the step's own stream: no joins per step
+        for b1, b2, labels in loader:
+            loss = step.step(b1.to(dev, non_blocking=True), b2.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
+            recs.append((loss.clone(), step.last_counts.clone(), labels.shape[0]))
+    torch.cuda.current_stream(dev).wait_stream(step.stream())
     metrics = initialize_metrics()
     for loss, counts, n in recs:
         c = counts.cpu()

@@ -65,8 +65,9 @@ class TrainStep:
         if not self.high_priority_chain:
             return self._step(x_d1, x_d2, labels)
         cur = torch.cuda.current_stream(x_d1.device)
-        if self._hp is None:
-            self._hp = torch.cuda.Stream(device=x_d1.device, priority=-1)
+        hp = self.stream(x_d1.device)
+        if cur.cuda_stream == hp.cuda_stream:              # the caller already runs its loop on the step's stream: no joins
+            return self._step(x_d1, x_d2, labels)
         self._hp.wait_stream(cur)
         with torch.cuda.stream(self._hp):
             loss = self._step(x_d1, x_d2, labels)
@@ -74,6 +75,14 @@ class TrainStep:
         for t in (loss, self.last_logits, self.last_counts):
             t.record_stream(cur)
         return loss
+
+    def stream(self, device=None):
+        """The high-priority stream the step's chain runs on.  A training loop that makes it the current stream
+        (``with torch.cuda.stream(step.stream()): ...``) saves the two cross-stream joins per step (~25 us of idle GPU)."""
+        if self._hp is None:
+            dev = device if device is not None else self.flat_params.device
+            self._hp = torch.cuda.Stream(device=dev, priority=-1)
+        return self._hp
 
     def _step(self, x_d1, x_d2, labels):
         model = self.model
