@@ -43,6 +43,7 @@ SIGNATURES = {
     'bdn_enc_skip_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_outc_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_outc_bn_bwd_apply': (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_set_tuning': (_i, [_i, _i]),

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
             for (int k = 0; k < NC; k++) accb[k] += g[k];
         }
         const uint4 uo = Unit<T>::pack(o);
-        *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
+        if (dA) *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
         if (bs) {                                             // BatchNorm-backward partial sums of this layer on the stored gradient
             Unit<T>::unpack(uo, o);
 #pragma unroll
@@ -334,7 +334,8 @@ extern "C" int bdn_outc_bwd_rows(int dtype, int B, int H, int W, int C) {
 
 extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
                             void* dA, float* dw, float* db, float* bs_partial, int B, int H, int W, int C, int ncls, void* stream) {
-    if (!dlogits || !z || !bn || !w || !dA || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
+    if (!dlogits || !z || !bn || !w || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
+    if (!dA && !bs_partial) BDN_FAIL(BDN_E_ARG, "outc_bwd: dA may be omitted only together with bs_partial (bdn_outc_bn_bwd_apply recomputes it)");
     if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream; const int npix = B * H * W;
     if (db == dw + (size_t)ncls * C) hipMemsetAsync(dw, 0, sizeof(float) * ncls * (C + 1), st);   // adjacent (flat gradient buffer): one fill
@@ -352,6 +353,79 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
         else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
     } else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
+    return BDN_OK;
+}
+
+// BatchNorm+ReLU backward of the layer in front of the classifier, with the classifier's data gradient RECOMPUTED from
+// dlogits (ncls values per pixel) instead of read back: dA = round_T(sum_k dl[k] w[k][c]) exactly as outc_bwd forms and
+// rounds it, then bn_bwd_apply's expression.  outc_bwd then need not store dA at all: 2 x B*H*W*C elements of HBM traffic
+// less, at a point of the step where nothing else runs.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ sums,
+                                T* __restrict__ dz, int npix, int hw, int pix_per_group, int pix_per_block, int C, int ncls) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int p_begin = blockIdx.x * pix_per_block, p_end = min(npix, p_begin + pix_per_block);
+    if (p_begin >= p_end) return;
+    const float invM = 1.f / (float)pix_per_group;
+    int gcur = -1;
+    float mean[EPU], inv[EPU], sc[EPU], sh[EPU], k0[EPU], k1[EPU], wk[NC][EPU];
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int i = 0; i < EPU; i++) wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f;
+    for (int p = p_begin + row; p < p_end; p += rows) {
+        const int g = p / pix_per_group;
+        if (g != gcur) {                                   // (blocks never straddle groups in practice; correct if they do)
+            gcur = g;
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                mean[i] = bn_row(bn, g, 0, C)[c + i]; inv[i] = bn_row(bn, g, 1, C)[c + i];
+                sc[i] = bn_row(bn, g, 2, C)[c + i]; sh[i] = bn_row(bn, g, 3, C)[c + i];
+                k0[i] = sums[((size_t)g * 2 + 0) * C + c + i] * invM;
+                k1[i] = sums[((size_t)g * 2 + 1) * C + c + i] * invM;
+            }
+        }
+        const int b = p / hw, q = p % hw;
+        float gl[NC], fz[EPU], o[EPU];
+#pragma unroll
+        for (int k = 0; k < NC; k++) gl[k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
+        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), fz);
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; k++) if (k < ncls) s = fmaf(gl[k], wk[k][i], s);
+            o[i] = s;
+        }
+        Unit<T>::unpack(Unit<T>::pack(o), o);              // the gradient as outc_bwd would have stored it
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+            const float gm = fmaf(fz[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
+            const float xhat = (fz[i] - mean[i]) * inv[i];
+            o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
+        }
+        *reinterpret_cast<uint4*>(dz + (size_t)p * C + c) = Unit<T>::pack(o);
+    }
+}
+
+extern "C" int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const float* w, const void* z, const float* bn,
+                                     int imgs_per_group, const float* sums, void* dz, int B, int H, int W, int C, int ncls, void* stream) {
+    if (!dlogits || !w || !z || !bn || !sums || !dz) BDN_FAIL(BDN_E_ARG, "outc_bn_bwd_apply: null pointer");
+    if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 1024 || 1024 % C || B <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || B % imgs_per_group)
+        BDN_FAIL(BDN_E_SHAPE, "outc_bn_bwd_apply: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int npix = B * H * W, epu = dtype == BDN_BF16 ? 8 : 4, rows = 256 / (C / epu);
+    int ppb = (npix + 2047) / 2048; if (ppb < 2 * rows) ppb = 2 * rows; ppb = (ppb + rows - 1) / rows * rows;
+    const unsigned grid = (npix + ppb - 1) / ppb;
+#define OUTC_APPLY(T_, NC_) hipLaunchKernelGGL((outc_bn_bwd_apply_kernel<T_, NC_>), dim3(grid), dim3(256), 0, st, dlogits, w, (const T_*)z, bn, sums, \
+                                               (T_*)dz, npix, H * W, imgs_per_group * H * W, ppb, C, ncls)
+    if (dtype == BDN_BF16) { if (ncls <= 2) OUTC_APPLY(bf16s, 2); else OUTC_APPLY(bf16s, OUTC_MAXCLS); }
+    else if (dtype == BDN_F32) { if (ncls <= 2) OUTC_APPLY(float, 2); else OUTC_APPLY(float, OUTC_MAXCLS); }
+    else BDN_FAIL(BDN_E_ARG, "outc_bn_bwd_apply: bad dtype");
+#undef OUTC_APPLY
+    BDN_CHECK_LAUNCH("outc_bn_bwd_apply");
     return BDN_OK;
 }
 

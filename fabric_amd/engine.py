@@ -162,6 +162,7 @@ class BiDateEngine:
         self._pack_desc = None
         self._packed_versions = None
         self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
+        self.fuse_head_bwd = True       # A/B switch: d4b's BatchNorm backward recomputes the classifier's data gradient from dlogits
         self.fuse_first_wgrad = True    # A/B switch: the first conv's BatchNorm backward inside its weight-gradient GEMM (bf16 only)
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
         self._diag_skip_wgrad = False
@@ -439,8 +440,9 @@ class BiDateEngine:
 
         # ---- classifier
         L4b = by['d4b']
-        dA = e(B, H, W, L4b.cout)
         fuse = self.fuse_bn_bwd_stats
+        head_fused = fuse and self.fuse_head_bwd     # the classifier's data gradient is recomputed by d4b's BatchNorm backward, never stored
+        dA = None if head_fused else e(B, H, W, L4b.cout)
         call('bdn_outc_bwd', self.dt, ptr(dlogits), ptr(ws.z['d4b']), ptr(ws.bn['d4b']), ptr(P['outc.conv.weight']),
              ptr(dA), ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), ptr(ws.stats) if fuse else None,
              B, H, W, L4b.cout, self.n_classes, st)
@@ -459,7 +461,14 @@ class BiDateEngine:
             ck = ENC_CH[k - 1]
             cprev = La.cin - ck
             late = self.wgrad_after_dgrad
-            dzb = bn_bwd(Lb, dA_ptr, ldA, B, B, fused_rows=rows_head if j == 4 else 0)
+            if j == 4 and head_fused:
+                dzb = e(B, hk, wk, Lb.cout)
+                call('bdn_bn_bwd_finalize', ptr(ws.bn[Lb.name]), 1, Lb.cout, ptr(ws.stats), rows_head, 1, ptr(sc['sums']),
+                     ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
+                call('bdn_outc_bn_bwd_apply', self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
+                     ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dzb), B, hk, wk, Lb.cout, self.n_classes, st)
+            else:
+                dzb = bn_bwd(Lb, dA_ptr, ldA, B, B, fused_rows=rows_head if j == 4 else 0)
             if not late:
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dAa, rows = dgrad(Lb, dzb, B, B, prev=La)

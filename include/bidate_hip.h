@@ -195,6 +195,12 @@ int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, cons
 /* dlogits: [B,ncls,H,W] f32 -> dA [B,H,W,C] (wrt relu(bn(z))), dw [ncls][C], db [ncls] (overwritten). */
 int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
                  void* dA, float* dw, float* db, float* bs_partial, int B, int H, int W, int C, int ncls, void* stream);
+/* BatchNorm+ReLU backward of the layer in front of the classifier with the classifier's data gradient recomputed from
+ * dlogits (outconv, models/unet_parts.py:83-90, after double_conv's BN+ReLU, :16-18): dz = bn_bwd(round(sum_k dlogits[k] w[k][c]), z)
+ * with `sums` from bdn_bn_bwd_finalize.  Call bdn_outc_bwd with dA = NULL (it still leaves the partial sums) and this instead
+ * of bdn_bn_bwd_apply: the gradient tensor in between is never written or read. */
+int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const float* w, const void* z, const float* bn,
+                          int imgs_per_group, const float* sums, void* dz, int B, int H, int W, int C, int ncls, void* stream);
 /* bs_partial: NULL, or f32 [bdn_outc_bwd_rows(dtype,B,H,W,C)][2][C]: BatchNorm-backward partial sums of the layer that
  * produced z (sum g, sum g*z on the stored dA) -> bdn_bn_bwd_apply(raw_moment = 1, one statistic group). */
 int bdn_outc_bwd_rows(int dtype, int B, int H, int W, int C);

@@ -503,6 +503,52 @@ def test_dgrad_with_fused_bn_bwd_stats(prec, case):
 
 
 @pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64, 2, 1), (4, 33, 20, 64, 2, 2), (2, 24, 24, 128, 3, 2), (2, 128, 128, 64, 2, 2)])
+def test_head_bn_bwd_recomputed_from_dlogits(prec, shape):
+    """bdn_outc_bwd(dA = NULL) + bdn_bn_bwd_finalize + bdn_outc_bn_bwd_apply == bdn_outc_bwd + bdn_bn_bwd_apply, bit for bit
+    (dz, sums, dgamma, dbeta): the classifier's data gradient is re-formed and re-rounded exactly as outc_bwd stores it."""
+    B, H, W, C, ncls, ipg = shape
+    dt, td = DT[prec]
+    G = B // ipg
+    lib = _lib.load()
+    z = rnd(prec, _rand((B, C, H, W), 501))
+    z_d = to_nhwc(prec, z)
+    bn = bn_table(G, C, 502)
+    bn1 = bn[:1].clone()                                   # outc_bwd works on one statistic group (the decoder's)
+    bn_use = bn if G > 1 else bn1
+    w_d = dev(_rand((ncls, C), 503, 0.2))
+    dl_d = dev(_rand((B, ncls, H, W), 504))
+    rows = lib.bdn_outc_bwd_rows(dt, B, H, W, C)
+    out = {}
+    for fused in (0, 1):
+        dA = torch.empty(B, H, W, C, dtype=td, device='cuda')
+        dw, db = torch.empty(ncls, C, device='cuda'), torch.empty(ncls, device='cuda')
+        part = torch.full((rows, 2, C), float('nan'), device='cuda')
+        bn_d = dev(bn1)
+        _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(),
+                  None if fused else dA.data_ptr(), dw.data_ptr(), db.data_ptr(), part.data_ptr(), B, H, W, C, ncls, st())
+        sums = torch.empty(1, 2, C, device='cuda')
+        dg, dbt = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        dz = torch.full((B, H, W, C), float('nan'), dtype=td, device='cuda')
+        if fused:
+            _lib.call('bdn_bn_bwd_finalize', bn_d.data_ptr(), 1, C, part.data_ptr(), rows, 1, sums.data_ptr(), dg.data_ptr(),
+                      dbt.data_ptr(), None, st())
+            _lib.call('bdn_outc_bn_bwd_apply', dt, dl_d.data_ptr(), w_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), B, sums.data_ptr(),
+                      dz.data_ptr(), B, H, W, C, ncls, st())
+        else:
+            _lib.call('bdn_bn_bwd_apply', dt, dA.data_ptr(), C, z_d.data_ptr(), bn_d.data_ptr(), B, B, H, W, C, part.data_ptr(), rows, 1,
+                      sums.data_ptr(), dg.data_ptr(), dbt.data_ptr(), dz.data_ptr(), None, st())
+        torch.cuda.synchronize()
+        out[fused] = (dz.float().cpu(), sums.cpu(), dg.cpu(), dbt.cpu())
+    assert torch.isfinite(out[1][0]).all()
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):                      # nobody would consume the gradient
+        _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), dev(bn1).data_ptr(), w_d.data_ptr(), None, dw.data_ptr(),
+                  db.data_ptr(), None, B, H, W, C, ncls, st())
+
+
+@pytest.mark.parametrize('prec', PRECS)
 def test_pack_weights_multi_equals_per_layer_pack(prec):
     """bdn_pack_weights_multi (one call for a list of layers; bf16 takes the LDS-tiled kernel for regular layers and the
     element-wise one for the rest) writes the same fragment-order images as bdn_pack_weights layer by layer."""

@@ -120,6 +120,26 @@ def test_train_step_matches_reference(golden_dir, name, prec):
 
 
 @pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
+def test_head_fusion_switch_leaves_every_gradient_unchanged(golden_dir, name):
+    """engine.fuse_head_bwd: d4b's BatchNorm backward recomputes the classifier's data gradient instead of reading it back --
+    same numbers (only the float-atomic classifier gradients may differ in the last bits between two runs)."""
+    g, c, x1, x2, lbl = _load(golden_dir, name)
+    grads = {}
+    for fused in (False, True):
+        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
+        model.engine().fuse_head_bwd = fused
+        _tversky_torch(model(x1, x2), lbl).backward()
+        torch.cuda.synchronize()
+        grads[fused] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        if k.startswith('outc.'):
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max(), k
+        else:
+            assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
 def test_first_layer_fused_weight_gradient_equals_two_kernel_path(golden_dir, name):
     """engine.fuse_first_wgrad (bf16): BatchNorm backward applied inside the first conv's weight-gradient GEMM.  Every other
     conv / BatchNorm gradient is produced by the same kernels (bit-equal); inc's conv weight differs only by summation order."""
