@@ -10,7 +10,8 @@ on RCCL's stream while the remaining dgrad / wgrad kernels keep the compute stre
 The gradients live in ONE flat buffer laid out in the order they complete during backward
 (engine.param_order), so a bucket is a contiguous slice and needs no packing copy.  xGMI is
 point to point (7 links per GPU): a ring all-reduce is bound by one link, so buckets are kept
-large (default 4 slices of ~13 MB) rather than many small NVSwitch-style ones.
+large (default 4 slices of ~13 MB, the last one split once more so that only ~1 MB is left for the end of backward)
+rather than many small NVSwitch-style ones.
 
 This module is pure torch.distributed logic and runs unchanged on CPU tensors with the gloo
 backend (tests/test_parallel_cpu.py, world_size 2).
@@ -49,7 +50,11 @@ class GradBucketer:
     keys_no_reduce: gradients that are identically zero on every rank (conv biases in front of a
     BatchNorm) -- they sit at the tail of the layout and are never communicated."""
 
-    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=(), enabled=True):
+    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=(), enabled=True, tail_bytes=1 << 20):
+        """n_buckets equal slices by bytes, plus one more cut in front of the last `tail_bytes` of gradients: the final
+        bucket cannot start before the very last weight gradient of backward exists, so its all-reduce is the one piece of
+        communication nothing can hide -- in BiDateNet the last megabyte is the four shallow encoder convs, while an equal
+        quarter (13 MB) would also have held back three deep layers that were ready a millisecond earlier."""
         self.layout, self.flat, self.group = layout, flat_grads, group
         self.enabled = enabled                      # False: purely local step even inside an initialised process group
         skip = set(keys_no_reduce)
@@ -71,7 +76,19 @@ class GradBucketer:
                 self.buckets.append((start, stop, cur))
                 cur, start = [], stop
         if cur:
-            self.buckets.append((start, self.reduce_end, cur))
+            # split the last bucket in front of its final `tail_bytes` (whole tensors only; never an empty half)
+            cut, acc = len(cur), 0
+            for i in range(len(cur) - 1, 0, -1):
+                acc += layout.slices[cur[i]][1] * 4
+                if acc > tail_bytes:
+                    break
+                cut = i
+            if tail_bytes > 0 and 0 < cut < len(cur):
+                mid = layout.slices[cur[cut]][0]
+                self.buckets.append((start, mid, cur[:cut]))
+                self.buckets.append((mid, self.reduce_end, cur[cut:]))
+            else:
+                self.buckets.append((start, self.reduce_end, cur))
         self.key_bucket = {k: i for i, (_, _, ks) in enumerate(self.buckets) for k in ks}
         self.reset()
 

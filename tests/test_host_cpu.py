@@ -115,7 +115,12 @@ lay = FlatLayout([(k, p.shape) for k, p in m.named_parameters()], order)
 flat = torch.zeros(lay.total)
 tail = [k for k in order if k.endswith('.bias') and k.split('.')[-2] in ('0', '3')]
 b = GradBucketer(lay, flat, n_buckets=4, keys_no_reduce=tail)
-assert len(b.buckets) == 4 and b.buckets[0][0] == 0 and b.buckets[-1][1] == b.reduce_end
+assert len(b.buckets) == 5 and b.buckets[0][0] == 0 and b.buckets[-1][1] == b.reduce_end
+assert all(b.buckets[i][1] == b.buckets[i + 1][0] for i in range(4))                 # contiguous, no gap or overlap
+assert (b.buckets[-1][1] - b.buckets[-1][0]) * 4 <= (1 << 20) < (b.buckets[-2][1] - b.buckets[-2][0]) * 4   # small tail
+assert sum(len(ks) for _, _, ks in b.buckets) == len(order) - len(tail)
+b4 = GradBucketer(lay, flat, n_buckets=4, keys_no_reduce=tail, tail_bytes=0)
+assert len(b4.buckets) == 4
 for step in range(2):
     for k in order:                       # "backward": gradients appear in layout order
         g = lay.view(flat, k)
