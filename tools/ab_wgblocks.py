@@ -10,7 +10,7 @@ B = 64
 x1 = torch.randn(B, 13, 128, 128, device='cuda'); x2 = torch.randn(B, 13, 128, 128, device='cuda')
 lbl = (torch.rand(B, 128, 128, device='cuda') < 0.1).to(torch.uint8)
 res = {v: [] for v in vals}
-for rep in range(3):
+for rep in range(int(os.environ.get("AB_REPS", "3"))):
     for v in vals:
         _lib.call('bdn_set_tuning', key, v)
         torch.manual_seed(0)
