@@ -42,9 +42,11 @@ SIGNATURES = {
     'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_enc_skip_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_outc_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'bdn_outc_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_outc_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'bdn_outc_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bn_bwd_apply': (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
+    'bdn_overlap_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_set_tuning': (_i, [_i, _i]),
     'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),

@@ -251,14 +251,14 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
 
 // backward: dA[p][c] = sum_k dl[k][p] w[k][c];  dw[k][c] = sum_p dl[k][p] a[p][c];  db[k] = sum_p dl[k][p]
 // Thread t owns channel unit t % CU (its filter taps, BN constants and dw accumulators live in registers)
-// and walks pixels t / CU, +rows, ...; block partials of dw/db are combined with f32 atomics on a zeroed
-// buffer (ncls*(C+1) addresses) -- the only float atomics on the training path.
+// and walks pixels t / CU, +rows, ...; the block partials of dw/db go to a workspace and are summed in a fixed order by
+// outc_dw_reduce_kernel (the first version added them with float atomics: the only non-deterministic bits of a step).
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
-                                const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ dw, float* __restrict__ db,
+                                const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ wpart,
                                 float* __restrict__ bs_partial, int npix, int hw, int C, int ncls) {
     constexpr int EPU = ET<T>::EPU;
-    extern __shared__ float sm[];                             // [ncls][C+1] block accumulators (+ [256][EPU][2] with bs_partial)
+    extern __shared__ float sm[];                             // [ncls][C+1] block sums + [256][EPU][2] reduction scratch
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     for (int i = tid; i < ncls * (C + 1); i += 256) sm[i] = 0.f;
     float sc[EPU], sh[EPU], wk[NC][EPU], acc[NC][EPU], accb[NC], t0[EPU], t1[EPU];
@@ -302,16 +302,30 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
             }
         }
     }
-    for (int k = 0; k < ncls; k++) {
+    // block sums of dw / db in a fixed order: per class every thread parks its partials in LDS, then one thread per
+    // channel adds the block's `rows` pixel rows in order (LDS atomics would make the last bits depend on wave timing)
+    {
+        float* red = sm + ncls * (C + 1);                     // [256][EPU] dw partials + [rows] db partials
 #pragma unroll
-        for (int i = 0; i < EPU; i++) atomicAdd(&sm[k * (C + 1) + c + i], acc[k][i]);   // LDS atomics: `rows` adds per address
-        if (cu == 0) atomicAdd(&sm[k * (C + 1) + C], accb[k]);
+        for (int k = 0; k < NC; k++) {
+            if (k < ncls) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < EPU; i++) red[tid * EPU + i] = acc[k][i];
+                if (cu == 0) red[256 * EPU + row] = accb[k];
+                __syncthreads();
+                for (int o = tid; o <= C; o += 256) {
+                    float v = 0.f;
+                    if (o < C) { const int ccu = o / EPU, i = o % EPU; for (int r = 0; r < rows; r++) v += red[(r * CU + ccu) * EPU + i]; }
+                    else for (int r = 0; r < rows; r++) v += red[256 * EPU + r];
+                    sm[k * (C + 1) + o] = v;
+                }
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < ncls * (C + 1); i += 256) {
-        const int k = i / (C + 1), cc = i % (C + 1);
-        if (cc < C) atomicAdd(&dw[k * C + cc], sm[i]); else atomicAdd(&db[k], sm[i]);
-    }
+    for (int i = tid; i < ncls * (C + 1); i += 256)        // block partial [ncls][C+1]; outc_dw_reduce_kernel sums the blocks in order
+        wpart[(size_t)blockIdx.x * ncls * (C + 1) + i] = sm[i];
     if (bs) {                                                 // bs_partial[block][2][C], fixed order
         float* sred = sm + ncls * (C + 1);
 #pragma unroll
@@ -326,33 +340,56 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
     }
 }
 
+// dw[k][c] / db[k] = sum over the blocks' partials, fixed order: one block per output value, 256 lanes stride the rows,
+// then an LDS tree.
+__global__ __launch_bounds__(256) void outc_dw_reduce_kernel(const float* __restrict__ wpart, int rows, int C, int ncls,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float sm[256];
+    const int o = blockIdx.x, n = ncls * (C + 1);
+    float a = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) a += wpart[(size_t)r * n + o];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int k = o / (C + 1), cc = o % (C + 1);
+        if (cc < C) dw[k * C + cc] = sm[0]; else db[k] = sm[0];
+    }
+}
+
 extern "C" int bdn_outc_bwd_rows(int dtype, int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 16 || C > 1024 || 1024 % C) return 0;
     const int per = 256 / (C / (dtype == BDN_BF16 ? 8 : 4)) * OUTC_BWD_ITERS;
     return (B * H * W + per - 1) / per;
 }
 
+extern "C" size_t bdn_outc_bwd_workspace_bytes(int dtype, int B, int H, int W, int C, int ncls) {
+    const int rows = bdn_outc_bwd_rows(dtype, B, H, W, C);
+    if (rows <= 0 || ncls < 1 || ncls > OUTC_MAXCLS) return 0;
+    return (size_t)rows * ncls * (C + 1) * sizeof(float);
+}
+
 extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
-                            void* dA, float* dw, float* db, float* bs_partial, int B, int H, int W, int C, int ncls, void* stream) {
-    if (!dlogits || !z || !bn || !w || !dw || !db) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
+                            void* dA, float* dw, float* db, float* bs_partial, float* ws, int B, int H, int W, int C, int ncls, void* stream) {
+    if (!dlogits || !z || !bn || !w || !dw || !db || !ws) BDN_FAIL(BDN_E_ARG, "outc_bwd: null pointer");
     if (!dA && !bs_partial) BDN_FAIL(BDN_E_ARG, "outc_bwd: dA may be omitted only together with bs_partial (bdn_outc_bn_bwd_apply recomputes it)");
     if (ncls < 1 || ncls > OUTC_MAXCLS || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "outc_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream; const int npix = B * H * W;
-    if (db == dw + (size_t)ncls * C) hipMemsetAsync(dw, 0, sizeof(float) * ncls * (C + 1), st);   // adjacent (flat gradient buffer): one fill
-    else {
-        hipMemsetAsync(dw, 0, sizeof(float) * ncls * C, st);
-        hipMemsetAsync(db, 0, sizeof(float) * ncls, st);
-    }
     const unsigned grid = bdn_outc_bwd_rows(dtype, B, H, W, C);
-    const size_t smem = sizeof(float) * (ncls * (C + 1) + (bs_partial ? 256 * (dtype == BDN_BF16 ? 8 : 4) * 2 : 0));
+    const size_t smem = sizeof(float) * (ncls * (C + 1) + 256 * (dtype == BDN_BF16 ? 8 : 4) * 2);
     if (dtype == BDN_BF16) {
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
-        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls);
+        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls);
     } else if (dtype == BDN_F32) {
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
-        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, dw, db, bs_partial, npix, H * W, C, ncls);
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls);
+        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls);
     } else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
+    hipLaunchKernelGGL(outc_dw_reduce_kernel, dim3(ncls * (C + 1)), dim3(256), 0, st, ws, (int)grid, C, ncls, dw, db);
+    BDN_CHECK_LAUNCH("outc_dw_reduce");
     return BDN_OK;
 }
 
@@ -431,11 +468,11 @@ extern "C" int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const floa
 
 // ============================================================ Tversky loss (utils/metrics.py:130-171, dims == (0,2))
 // sums[k][c][w], k = 0 TP, 1 FP, 2 FN, reduced over batch and H for every (class, column w).
-// pass 1: grid (B*H rows) -> atomics on [3][ncls][W] (one add per row and address);  pass 2: single block
-// loss + coefficient tables;  pass 3: dlogits.
+// pass 1: grid (column blocks x row blocks) -> per-block partial sums;  pass 2: single block adds the blocks in a fixed
+// order (no float atomics: the loss and dlogits are the same bits every run), then loss + coefficient tables;  pass 3: dlogits.
 template <int NC>
 __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
-                                    float* __restrict__ sums, int32_t* __restrict__ counts, int B, int ncls, int H, int W,
+                                    float* __restrict__ part, int32_t* __restrict__ pcounts, int B, int ncls, int H, int W,
                                     int rows_per_block, int We) {
     // block = 256 threads = RL row lanes x CW columns (CW = min(W rounded up to a power of two, 256));
     // grid.x = column blocks, grid.y = row blocks
@@ -475,6 +512,9 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
         sm[(rl * 3 * NC + 2 * NC + k) * CW + cl] = fn[k];
     }
     __syncthreads();
+    // block partials, no atomics: part[row block][cell] (cells [3][ncls][W]) or part[block][3*NC] when the columns are
+    // reduced too; tversky_finish_kernel adds the blocks in a fixed order.  pcounts[block][4] likewise.
+    const int nblk_lin = blockIdx.y * gridDim.x + blockIdx.x;
     if (We == W) {
         if (rl == 0 && x < W)
             for (int k = 0; k < ncls; k++)
@@ -482,10 +522,10 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
                 for (int j = 0; j < 3; j++) {
                     float v = 0.f;
                     for (int r = 0; r < RL; r++) v += sm[(r * 3 * NC + j * NC + k) * CW + cl];
-                    atomicAdd(&sums[(j * ncls + k) * W + x], v);
+                    part[(size_t)blockIdx.y * 3 * ncls * W + (j * ncls + k) * W + x] = v;
                 }
     } else {
-        // [B,1,H,W] labels: the reference reduces over the columns too (dims == (0,2,3)); one atomic per block and address
+        // [B,1,H,W] labels: the reference reduces over the columns too (dims == (0,2,3))
         const int tid = rl + RL * cl;
         if (tid < 3 * NC) {
             float v = 0.f;
@@ -494,33 +534,66 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
                 if (blockIdx.x * CW + c < W) v += sm[(r * 3 * NC + tid) * CW + c];
             }
             const int j = tid / NC, k = tid % NC;
-            if (k < ncls) atomicAdd(&sums[j * ncls + k], v);
+            if (k < ncls) part[(size_t)nblk_lin * 3 * ncls + j * ncls + k] = v;
         }
     }
-    if (counts) {
+    {
         int* ism = reinterpret_cast<int*>(sm);
         __syncthreads();
         const int tid = rl * CW + cl;
         ism[tid * 4 + 0] = c_tp; ism[tid * 4 + 1] = c_fp; ism[tid * 4 + 2] = c_fn; ism[tid * 4 + 3] = c_ok;
         __syncthreads();
-        if (tid < 4) { int v = 0; for (int i = 0; i < 256; i++) v += ism[i * 4 + tid]; atomicAdd(&counts[tid], v); }
+        if (tid < 4) { int v = 0; for (int i = 0; i < 256; i++) v += ism[i * 4 + tid]; pcounts[nblk_lin * 4 + tid] = v; }
     }
 }
 
-// loss = 1 - mean_{c,w} TP/(TP + a FP + b FN + eps).  Overwrites sums[0] with 1/D and sums[1] with TP/D^2.
-__global__ void tversky_finish_kernel(float* __restrict__ sums, float alpha, float beta, float eps, int ncls, int W, float* __restrict__ loss) {   // W = effective width (1 when the columns are reduced too)
+// sums[cell] = sum over the nblk block partials (cell-major rows of `part`), fixed order: thread = (float4 of cells or one
+// cell, block lane); then loss = 1 - mean_{c,w} TP/(TP + a FP + b FN + eps).  Overwrites sums[0] with 1/D and sums[1] with TP/D^2.
+__global__ __launch_bounds__(1024) void tversky_finish_kernel(float* __restrict__ sums, const float* __restrict__ part, int nblk,
+                                      const int32_t* __restrict__ pcounts, int ncblk, int32_t* __restrict__ counts,
+                                      float alpha, float beta, float eps, int ncls, int W, float* __restrict__ loss) {   // W = effective width (1 when the columns are reduced too)
     __shared__ double red[256];
-    double acc = 0.0;
-    const int n = ncls * W;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float tp = sums[i], fp = sums[n + i], fn = sums[2 * n + i];
-        const float D = tp + alpha * fp + beta * fn + eps;
-        acc += (double)(tp / D);
-        sums[i] = 1.f / D; sums[n + i] = tp / (D * D);
+    __shared__ float4 lane_sums[1024];
+    const int n = 3 * ncls * W, tid = threadIdx.x;
+    if (n % 4 == 0 && n / 4 <= 1024) {
+        const int n4 = n / 4, LN = 1024 / n4 > 0 ? (1024 / n4 > 16 ? 16 : 1024 / n4) : 1;       // block lanes per float4 of cells
+        const int q = tid % n4, l = tid / n4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < LN) {
+#pragma unroll 8
+            for (int b = l; b < nblk; b += LN) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * n + 4 * q);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            lane_sums[tid] = a;
+        }
+        __syncthreads();
+        if (l == 0) {
+            for (int k = 1; k < LN; k++) { const float4 v = lane_sums[k * n4 + q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+            *reinterpret_cast<float4*>(sums + 4 * q) = a;
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            float a = 0.f;
+            for (int b = 0; b < nblk; b++) a += part[(size_t)b * n + i];
+            sums[i] = a;
+        }
     }
-    red[threadIdx.x] = acc; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) *loss = (float)(1.0 - red[0] / n);
+    if (counts && tid < 4) { int v = 0; for (int b = 0; b < ncblk; b++) v += pcounts[b * 4 + tid]; counts[tid] = v; }
+    __syncthreads();
+    double acc = 0.0;
+    const int nc = ncls * W;
+    if (tid < 256)
+        for (int i = tid; i < nc; i += 256) {
+            const float tp = sums[i], fp = sums[nc + i], fn = sums[2 * nc + i];
+            const float D = tp + alpha * fp + beta * fn + eps;
+            acc += (double)(tp / D);
+            sums[i] = 1.f / D; sums[nc + i] = tp / (D * D);
+        }
+    if (tid < 256) red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    if (tid == 0) *loss = (float)(1.0 - red[0] / nc);
 }
 
 __global__ void tversky_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
@@ -553,6 +626,25 @@ __global__ void tversky_bwd_kernel(const float* __restrict__ logits, const uint8
     for (int k = 0; k < OUTC_MAXCLS; k++) if (k < ncls) dlogits[(b * ncls + k) * hw + q] = l[k] * (dp[k] - dot);
 }
 
+struct OverlapPlan { int We, CW, RL, rpb, gx, gy, nblk, n; };
+static OverlapPlan overlap_plan(int B, int ncls, int H, int W, int reduce_w) {
+    OverlapPlan p;
+    p.We = reduce_w ? 1 : W;
+    p.CW = 1; while (p.CW < W && p.CW < 256) p.CW *= 2;
+    p.RL = 256 / p.CW;
+    const int rows = B * H;
+    p.rpb = (rows + 255) / 256; if (p.rpb < p.RL) p.rpb = p.RL;                 // ~256 row blocks
+    p.gx = (W + p.CW - 1) / p.CW; p.gy = (rows + p.rpb - 1) / p.rpb;
+    p.nblk = reduce_w ? p.gx * p.gy : p.gy;                                     // partial rows the finish kernel adds up
+    p.n = 3 * ncls * p.We;
+    return p;
+}
+extern "C" size_t bdn_overlap_workspace_bytes(int B, int ncls, int H, int W, int reduce_w) {
+    if (B <= 0 || H <= 0 || W <= 0 || ncls < 2 || ncls > OUTC_MAXCLS) return 0;
+    const OverlapPlan p = overlap_plan(B, ncls, H, W, reduce_w);
+    return sizeof(float) * ((size_t)p.n * (p.nblk + 1) + 8) + sizeof(int32_t) * 4 * p.gx * p.gy;
+}
+
 extern "C" int bdn_overlap_loss(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
                                 int reduce_w, float* ws, float* loss, int32_t* counts, float* dlogits,
                                 int B, int ncls, int H, int W, void* stream) {
@@ -560,21 +652,15 @@ extern "C" int bdn_overlap_loss(const float* logits, const uint8_t* labels, floa
     if (ncls < 2 || ncls > OUTC_MAXCLS) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: ncls=%d unsupported (2..%d)", ncls, OUTC_MAXCLS);
     if (B <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const int We = reduce_w ? 1 : W;
-    if (counts && (const void*)counts == (const void*)(ws + (size_t)3 * ncls * We))           // counts right behind the sums: one fill
-        hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * We + sizeof(int32_t) * 4, st);
-    else {
-        hipMemsetAsync(ws, 0, sizeof(float) * 3 * ncls * We, st);
-        if (counts) hipMemsetAsync(counts, 0, sizeof(int32_t) * 4, st);
-    }
-    int CW = 1; while (CW < W && CW < 256) CW *= 2;
-    const int RL = 256 / CW, rows = B * H;
-    int rpb = (rows + 255) / 256; if (rpb < RL) rpb = RL;                       // ~256 row blocks
-    dim3 grid((W + CW - 1) / CW, (rows + rpb - 1) / rpb), block(RL, CW);
-    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, ws, counts, B, ncls, H, W, rpb, We);
-    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, ws, counts, B, ncls, H, W, rpb, We);
+    const OverlapPlan p = overlap_plan(B, ncls, H, W, reduce_w);
+    const int We = p.We;
+    float* part = ws + p.n;                                                    // [nblk][n] block partials behind the n final sums
+    int32_t* pcounts = reinterpret_cast<int32_t*>(part + (size_t)p.nblk * p.n);  // [gx*gy][4]
+    dim3 grid(p.gx, p.gy), block(p.RL, p.CW);
+    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, part, pcounts, B, ncls, H, W, p.rpb, We);
+    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, part, pcounts, B, ncls, H, W, p.rpb, We);
     BDN_CHECK_LAUNCH("tversky_sums");
-    hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(256), 0, st, ws, alpha, beta, eps, ncls, We, loss);
+    hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(1024), 0, st, ws, part, p.nblk, pcounts, p.gx * p.gy, counts, alpha, beta, eps, ncls, We, loss);
     BDN_CHECK_LAUNCH("tversky_finish");
     if (dlogits) {
         hipLaunchKernelGGL(tversky_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, logits, labels, ws, alpha, beta, dlogits, B, ncls, H, W, We);

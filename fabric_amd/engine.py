@@ -129,7 +129,15 @@ class Workspace:
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
         self.n_wg1 = lib.bdn_wgrad_workspace_bytes(2 * B, H, W, L1.cout, L1.cin, B) // 4
         self._bwd = None
+        self._outc_ws = None
         self.logits = None
+
+    def outc_ws(self, eng):
+        """Scratch of bdn_outc_bwd (per-block partial classifier gradients)."""
+        if self._outc_ws is None:
+            n = _lib.load().bdn_outc_bwd_workspace_bytes(eng.dt, self.B, self.H, self.W, eng.layers[-1].cout, eng.n_classes)
+            self._outc_ws = torch.empty(max(n // 4, 1), dtype=torch.float32, device=self.x0.device)
+        return self._outc_ws
 
     def bwd_scratch(self, device):
         if self._bwd is None:
@@ -445,7 +453,7 @@ class BiDateEngine:
         dA = None if head_fused else e(B, H, W, L4b.cout)
         call('bdn_outc_bwd', self.dt, ptr(dlogits), ptr(ws.z['d4b']), ptr(ws.bn['d4b']), ptr(P['outc.conv.weight']),
              ptr(dA), ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), ptr(ws.stats) if fuse else None,
-             B, H, W, L4b.cout, self.n_classes, st)
+             ptr(ws.outc_ws(self)), B, H, W, L4b.cout, self.n_classes, st)
         rows_head = _lib.load().bdn_outc_bwd_rows(self.dt, B, H, W, L4b.cout) if fuse else 0
         ready(['outc.conv.weight', 'outc.conv.bias'])
         # ---- decoder

@@ -91,10 +91,10 @@ class TrainStep:
         logits, ws = eng.forward(x_d1, x_d2, P, training=True)
         B, C, H, W = logits.shape
         dev = logits.device
-        if self._tv is None or self._tv[3] != 3 * C * W:
-            buf = torch.empty(3 * C * W + 4, dtype=torch.float32, device=dev)
-            # the TP/FP/FN/TN counters sit right behind the Tversky sums, so the library clears both with one fill
-            self._tv = (buf, torch.empty((), dtype=torch.float32, device=dev), buf[3 * C * W:].view(torch.int32), 3 * C * W)
+        if self._tv is None or self._tv[3] != (B, C, H, W):
+            n = _lib.load().bdn_overlap_workspace_bytes(B, C, H, W, 0) // 4
+            self._tv = (torch.empty(n, dtype=torch.float32, device=dev), torch.empty((), dtype=torch.float32, device=dev),
+                        torch.empty(4, dtype=torch.int32, device=dev), (B, C, H, W))
         tvws, loss, counts, _ = self._tv
         if labels.dtype != torch.uint8:
             labels = labels.to(torch.uint8)

@@ -38,7 +38,7 @@ class _OverlapFunction(torch.autograd.Function):
         B, C, H, W = logits.shape
         lg = logits.detach().contiguous().float()
         lb, reduce_w = _check_labels(logits, labels)
-        ws = torch.empty(3 * C * W + 8, dtype=torch.float32, device=lg.device)
+        ws = torch.empty(_lib.load().bdn_overlap_workspace_bytes(B, C, H, W, reduce_w) // 4, dtype=torch.float32, device=lg.device)
         loss = torch.empty((), dtype=torch.float32, device=lg.device)
         counts = torch.empty(4, dtype=torch.int32, device=lg.device)
         dl = torch.empty_like(lg)

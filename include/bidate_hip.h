@@ -192,9 +192,11 @@ int bdn_enc_skip_bwd_rows(int dtype, int B, int H, int W, int C);
  * logits: [B,ncls,H,W] f32 NCHW (the reference's output layout). */
 int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, const float* b,
                  float* logits, int B, int H, int W, int C, int ncls, void* stream);
-/* dlogits: [B,ncls,H,W] f32 -> dA [B,H,W,C] (wrt relu(bn(z))), dw [ncls][C], db [ncls] (overwritten). */
+/* dlogits: [B,ncls,H,W] f32 -> dA [B,H,W,C] (wrt relu(bn(z))), dw [ncls][C], db [ncls] (overwritten).
+ * ws: bdn_outc_bwd_workspace_bytes() of scratch -- the blocks' partial dw / db, summed in a fixed order (deterministic). */
+size_t bdn_outc_bwd_workspace_bytes(int dtype, int B, int H, int W, int C, int ncls);
 int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn, const float* w,
-                 void* dA, float* dw, float* db, float* bs_partial, int B, int H, int W, int C, int ncls, void* stream);
+                 void* dA, float* dw, float* db, float* bs_partial, float* ws, int B, int H, int W, int C, int ncls, void* stream);
 /* BatchNorm+ReLU backward of the layer in front of the classifier with the classifier's data gradient recomputed from
  * dlogits (outconv, models/unet_parts.py:83-90, after double_conv's BN+ReLU, :16-18): dz = bn_bwd(round(sum_k dlogits[k] w[k][c]), z)
  * with `sums` from bdn_bn_bwd_finalize.  Call bdn_outc_bwd with dA = NULL (it still leaves the partial sums) and this instead
@@ -206,9 +208,11 @@ int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const float* w, const
 int bdn_outc_bwd_rows(int dtype, int B, int H, int W, int C);
 
 /* ---- TverskyLoss.forward, utils/metrics.py:130-171, for [B,H,W] labels (dims == (0,2)) ----
- * labels: uint8 [B,H,W].  ws: f32 workspace of 3*ncls*W + 8 floats.
+ * labels: uint8 [B,H,W].  ws: bdn_overlap_workspace_bytes(B, ncls, H, W, 0) bytes of f32 scratch (16-byte aligned): the
+ * blocks' partial sums are added in a fixed order, no float atomics -- loss and dlogits are the same bits on every run.
  * loss: f32 scalar.  counts: NULL or int32[4] = {TP, FP, FN, correct} of argmax(logits) vs labels
  * (class 1 positive; train.py:96-106).  dlogits: NULL or [B,ncls,H,W] = d loss / d logits. */
+size_t bdn_overlap_workspace_bytes(int B, int ncls, int H, int W, int reduce_w);
 int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
                 float* ws, float* loss, int32_t* counts, float* dlogits,
                 int B, int ncls, int H, int W, void* stream);
@@ -218,7 +222,8 @@ int bdn_tversky(const float* logits, const uint8_t* labels, float alpha, float b
  *   TverskyLoss(alpha, beta, eps) as is;  jaccard_loss(eps) = (1, 1, eps);  dice_loss(eps) = (0.5, 0.5, eps / 2)
  *   (2I / (2I + FP + FN + eps), utils/metrics.py:80-83).
  * reduce_w = 0: [B,H,W] labels, reference dims == (0,2): one cell per (class, column);
- * reduce_w = 1: [B,1,H,W] labels, dims == (0,2,3): one cell per class.  Other arguments as bdn_tversky. */
+ * reduce_w = 1: [B,1,H,W] labels, dims == (0,2,3): one cell per class.  ws: bdn_overlap_workspace_bytes(.., reduce_w).
+ * Other arguments as bdn_tversky. */
 int bdn_overlap_loss(const float* logits, const uint8_t* labels, float alpha, float beta, float eps,
                      int reduce_w, float* ws, float* loss, int32_t* counts, float* dlogits,
                      int B, int ncls, int H, int W, void* stream);

@@ -350,13 +350,16 @@ def test_outc_fwd_bwd(prec, shape):
     dl_d = dev(dl)
     rows = _lib.load().bdn_outc_bwd_rows(dt, B, H, W, C)
     part = torch.full((rows, 2, C), float('nan'), device='cuda')
+    wsz = _lib.load().bdn_outc_bwd_workspace_bytes(dt, B, H, W, C, ncls) // 4
+    ows = torch.full((wsz,), float('nan'), device='cuda')
     _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), dA.data_ptr(),
-              dw.data_ptr(), db.data_ptr(), part.data_ptr(), B, H, W, C, ncls, st())
+              dw.data_ptr(), db.data_ptr(), part.data_ptr(), ows.data_ptr(), B, H, W, C, ncls, st())
     dA2 = torch.empty_like(dA)
+    dw2, db2 = torch.full_like(dw, 5.0), torch.full_like(db, 5.0)
     _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), dA2.data_ptr(),
-              dw.data_ptr(), db.data_ptr(), None, B, H, W, C, ncls, st())
+              dw2.data_ptr(), db2.data_ptr(), None, ows.data_ptr(), B, H, W, C, ncls, st())
     torch.cuda.synchronize()
-    assert torch.equal(dA, dA2)
+    assert torch.equal(dA, dA2) and torch.equal(dw, dw2) and torch.equal(db, db2)       # fixed-order sums: same bits every time
     gm = from_nhwc(dA).double() * (bnrelu_ref(prec, z, bn, B) > 0)          # fused BatchNorm-backward partial sums
     got = part.double().sum(0).cpu()
     assert_close('sum g', got[0].float(), gm.sum((0, 2, 3)).float(), 2e-5, abs_floor=1e-4)
@@ -375,7 +378,7 @@ def test_tversky(shape):
     lg = logits.double().requires_grad_(True)
     ref = O.tversky_loss(lg, labels.long(), 0.1, 0.9)
     ref.backward()
-    ws = torch.empty(3 * ncls * W + 8, device='cuda')
+    ws = torch.empty(_lib.load().bdn_overlap_workspace_bytes(B, ncls, H, W, 0) // 4, device='cuda')
     loss = torch.empty(1, device='cuda')
     counts = torch.empty(4, dtype=torch.int32, device='cuda')
     dl = torch.empty(B, ncls, H, W, device='cuda')
@@ -398,7 +401,7 @@ def test_tversky_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, 'g5_losses.npz'))
     logits, labels = torch.from_numpy(g['logits']), torch.from_numpy(g['labels'])
     B, ncls, H, W = logits.shape
-    ws = torch.empty(3 * ncls * W + 8, device='cuda')
+    ws = torch.empty(_lib.load().bdn_overlap_workspace_bytes(B, ncls, H, W, 0) // 4, device='cuda')
     loss = torch.empty(1, device='cuda')
     dl = torch.empty(B, ncls, H, W, device='cuda')
     lg_d, lb_d = dev(logits), labels.cuda()
@@ -525,8 +528,9 @@ def test_head_bn_bwd_recomputed_from_dlogits(prec, shape):
         dw, db = torch.empty(ncls, C, device='cuda'), torch.empty(ncls, device='cuda')
         part = torch.full((rows, 2, C), float('nan'), device='cuda')
         bn_d = dev(bn1)
+        ows = torch.empty(lib.bdn_outc_bwd_workspace_bytes(dt, B, H, W, C, ncls) // 4, device='cuda')
         _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(),
-                  None if fused else dA.data_ptr(), dw.data_ptr(), db.data_ptr(), part.data_ptr(), B, H, W, C, ncls, st())
+                  None if fused else dA.data_ptr(), dw.data_ptr(), db.data_ptr(), part.data_ptr(), ows.data_ptr(), B, H, W, C, ncls, st())
         sums = torch.empty(1, 2, C, device='cuda')
         dg, dbt = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
         dz = torch.full((B, H, W, C), float('nan'), dtype=td, device='cuda')
@@ -545,7 +549,7 @@ def test_head_bn_bwd_recomputed_from_dlogits(prec, shape):
         assert torch.equal(a, b)
     with pytest.raises(RuntimeError):                      # nobody would consume the gradient
         _lib.call('bdn_outc_bwd', dt, dl_d.data_ptr(), z_d.data_ptr(), dev(bn1).data_ptr(), w_d.data_ptr(), None, dw.data_ptr(),
-                  db.data_ptr(), None, B, H, W, C, ncls, st())
+                  db.data_ptr(), None, ows.data_ptr(), B, H, W, C, ncls, st())
 
 
 @pytest.mark.parametrize('prec', PRECS)

@@ -21,10 +21,11 @@ dA = torch.empty_like(z); dw = torch.empty(2, 64, device='cuda'); db = torch.emp
 gb = lambda *ts: sum(t.numel() * t.element_size() for t in ts) / 1e9
 t = timeit(lambda: _lib.call('bdn_outc_fwd', dt, z.data_ptr(), bn.data_ptr(), w.data_ptr(), b.data_ptr(), logits.data_ptr(), B, S, S, 64, 2, st))
 print(f'outc_fwd {t:7.1f} us  {gb(z, logits) / t * 1e6:6.0f} GB/s')
-t = timeit(lambda: _lib.call('bdn_outc_bwd', dt, dl.data_ptr(), z.data_ptr(), bn.data_ptr(), w.data_ptr(), dA.data_ptr(), dw.data_ptr(), db.data_ptr(), None, B, S, S, 64, 2, st))
+ows = torch.empty(_lib.load().bdn_outc_bwd_workspace_bytes(dt, B, S, S, 64, 2) // 4, device='cuda')
+t = timeit(lambda: _lib.call('bdn_outc_bwd', dt, dl.data_ptr(), z.data_ptr(), bn.data_ptr(), w.data_ptr(), dA.data_ptr(), dw.data_ptr(), db.data_ptr(), None, ows.data_ptr(), B, S, S, 64, 2, st))
 print(f'outc_bwd {t:7.1f} us  {gb(z, dl, dA) / t * 1e6:6.0f} GB/s')
 lbl = (torch.rand(B, S, S, device='cuda') < 0.1).to(torch.uint8)
-ws = torch.empty(3 * 2 * S + 8, device='cuda'); loss = torch.empty(1, device='cuda'); cnt = torch.empty(4, dtype=torch.int32, device='cuda')
+ws = torch.empty(_lib.load().bdn_overlap_workspace_bytes(B, 2, S, S, 0) // 4, device='cuda'); loss = torch.empty(1, device='cuda'); cnt = torch.empty(4, dtype=torch.int32, device='cuda')
 t = timeit(lambda: _lib.call('bdn_tversky', logits.data_ptr(), lbl.data_ptr(), 0.1, 0.9, 1e-7, ws.data_ptr(), loss.data_ptr(), cnt.data_ptr(), dl.data_ptr(), B, 2, S, S, st))
 print(f'tversky  {t:7.1f} us  {gb(logits, logits, dl, lbl, lbl) / t * 1e6:6.0f} GB/s')
 x1 = torch.randn(B, 13, S, S, device='cuda'); x0 = torch.empty(2 * B, S, S, 16, device='cuda', dtype=td)
