@@ -11,6 +11,12 @@ LIB_PATH = os.environ.get('BIDATE_LIB') or os.path.join(_HERE, 'csrc', 'libbidat
 
 BDN_F32, BDN_BF16 = 0, 1
 IN_PLAIN, IN_BNRELU = 0, 1
+WG_SIMPLE, WG_PIPE, WG_DMA = 1, 2, 3
+
+
+def wg_flags(phases=3, kernel=0, blocks=0):
+    """BDN_WG_FLAGS of include/bidate_hip.h."""
+    return phases | (kernel << 8) | (blocks << 16)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -26,7 +32,8 @@ SIGNATURES = {
     'bdn_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_wgrad_ex': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'bdn_conv3x3_wgrad_variant': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    'bdn_conv3x3_wgrad_variant': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    'bdn_wgrad_workspace_bytes_ex': (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_wgrad_bnbwd_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_wgrad_bnbwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_finalize_workspace_bytes': (_sz, [_i, _i, _i]),
@@ -34,6 +41,7 @@ SIGNATURES = {
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_bnrelu': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_product_pool': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -48,7 +56,6 @@ SIGNATURES = {
     'bdn_outc_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_overlap_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'bdn_set_tuning': (_i, [_i, _i]),
     'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 #include "../../include/bidate_hip.h"
 
 typedef uint16_t bf16s;                                   // bf16 storage
@@ -16,6 +17,15 @@ void bdn_set_error(const char* fmt, ...);
 #define BDN_FAIL(code, ...) do { bdn_set_error(__VA_ARGS__); return (code); } while (0)
 #define BDN_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) BDN_FAIL(BDN_E_HIP, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+// Raise a kernel's dynamic-LDS limit exactly once per instantiation (the macro sits inside a function template, so the
+// statics are per kernel), safely under concurrent first calls from several threads: std::call_once, the result is kept.
+#define BDN_SET_SMEM_ONCE(kern_, bytes_, name_) do {                                                           \
+    static std::once_flag once_; static hipError_t err_ = hipSuccess;                                         \
+    std::call_once(once_, [&] { err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_),              \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (bytes_)); }); \
+    if (err_ != hipSuccess) BDN_FAIL(BDN_E_HIP, "%s: hipFuncSetAttribute(%d): %s", name_, (int)(bytes_), hipGetErrorString(err_)); \
+} while (0)
 
 // ---------------------------------------------------------------- element traits
 template <typename T> struct ET;

@@ -421,12 +421,7 @@ static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
         return BDN_OK;
     }
     auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "conv3x3: hipFuncSetAttribute(%d): %s", CF::SMEM, hipGetErrorString(e));
-        attr_set = true;
-    }
+    BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
     hipLaunchKernelGGL(kern, dim3(n_mtiles * b.n_ntiles), dim3(256), CF::SMEM, st, b);

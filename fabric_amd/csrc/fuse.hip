@@ -62,6 +62,42 @@ extern "C" int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int im
     return BDN_OK;
 }
 
+// ============================================================ a = relu(bn(z)) materialised (nn.BatchNorm2d + nn.ReLU, models/unet_parts.py:14-15)
+// The 3x3 consumers normally apply this while staging; the LDS-DMA weight-gradient kernel cannot (its operands never pass
+// through registers), so the training schedule writes the post-activation tensor once per layer, on the weight-gradient
+// stream.  Same rounding as every on-load application (act1), so the GEMM operands are bit-identical.
+template <typename T>
+__global__ void bnrelu_kernel(const T* __restrict__ z, const float* __restrict__ bn, int ppg, int bpg, T* __restrict__ out, int C) {
+    constexpr int EPU = ET<T>::EPU;
+    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int g = blockIdx.x / bpg, bg = blockIdx.x % bpg;
+    float sc[EPU], sh[EPU];
+    load_consts<T>(bn_row(bn, g, 2, C) + c, sc); load_consts<T>(bn_row(bn, g, 3, C) + c, sh);
+    const int p_end = min(ppg, (bg + 1) * rows * ITERS);
+    const size_t base = (size_t)g * ppg;
+    for (int p = bg * rows * ITERS + row; p < p_end; p += rows) {
+        const uint4 v = *reinterpret_cast<const uint4*>(z + (base + p) * C + c);
+        *reinterpret_cast<uint4*>(out + (base + p) * C + c) = bnrelu_unit<T>(v, sc, sh);
+    }
+}
+
+extern "C" int bdn_bnrelu(int dtype, const void* z, const float* bn, int imgs_per_group, void* out,
+                          int N, int H, int W, int C, void* stream) {
+    if (!z || !bn || !out) BDN_FAIL(BDN_E_ARG, "bnrelu: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || C % 16 || C > 1024 || 1024 % C || imgs_per_group <= 0 || N % imgs_per_group)
+        BDN_FAIL(BDN_E_SHAPE, "bnrelu: bad shape N=%d H=%d W=%d C=%d imgs_per_group=%d", N, H, W, C, imgs_per_group);
+    if ((size_t)imgs_per_group * H * W >= ((size_t)1 << 31)) BDN_FAIL(BDN_E_SHAPE, "bnrelu: group too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int G = N / imgs_per_group, ppg = imgs_per_group * H * W;
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS, bpg = (ppg + per - 1) / per;
+        hipLaunchKernelGGL(bnrelu_kernel<bf16s>, dim3(G * bpg), dim3(256), 0, st, (const bf16s*)z, bn, ppg, bpg, (bf16s*)out, C); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS, bpg = (ppg + per - 1) / per;
+        hipLaunchKernelGGL(bnrelu_kernel<float>, dim3(G * bpg), dim3(256), 0, st, (const float*)z, bn, ppg, bpg, (float*)out, C); }
+    else BDN_FAIL(BDN_E_ARG, "bnrelu: bad dtype");
+    BDN_CHECK_LAUNCH("bnrelu");
+    return BDN_OK;
+}
+
 // ============================================================ date fusion relu(a_d2 * a_d1)
 template <typename T>
 __global__ void fuse_product_kernel(const T* __restrict__ z, const float* __restrict__ bn, T* __restrict__ f, int npix, int C) {

@@ -439,71 +439,90 @@ __global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
 template <bool USE_BN>
 static int launch_wgrad2(const WgradArgs& a, hipStream_t st) {
     auto kern = wgrad2_kernel<USE_BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2::SMEM);
-        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad2: hipFuncSetAttribute(%d): %s", Wg2::SMEM, hipGetErrorString(e));
-        attr_set = true;
-    }
+    BDN_SET_SMEM_ONCE(kern, Wg2::SMEM, "wgrad2");
     hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), Wg2::SMEM, st, a);
     BDN_CHECK_LAUNCH("wgrad2");
     return BDN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// wgrad3: the same pipeline with EIGHT waves per block (two per SIMD) on a 128(co) x 64(ci) tile.  The BatchNorm'd
-// activation patch is staged once for four co-waves instead of two, so the staging work per MFMA (the 40 % of wgrad2's
-// time that is not MFMA + LDS reads) drops by a third, and the second wave of every SIMD issues into the other's
-// staging instructions.  One register set (256 registers per wave), refilled in two stages: the patch units right after
-// their last LDS store (row 4), the dz units after theirs (row 9).  LDS: 2 x (192 x 192 B patch + 128 x 320 B dz) = 152 KB.
-struct Wg3 {
-    static constexpr int PW = 18, PH = 10, STR = 192, DSTR = 320;
-    static constexpr int PATCH_BYTES = 3 * 64 * STR;             // 180 patch pixels padded to the 192 unit slots the threads own
-    static constexpr int DZ_BYTES = 128 * DSTR;                  // 256 B of dz per pixel + 64 B so that four pixels cover all banks
+// wgrad6 (BDN_WG_DMA): wgrad2's tile, split plan, LDS image and MFMA order (results are bit-identical), but the operands
+// never pass through registers: both the dz tile and the activation halo patch go HBM/L2 -> LDS by
+// `buffer_load_dwordx4 ... lds` (LDS-DMA).  wgrad2's anatomy showed that with one wave per SIMD every
+// staging instruction -- global loads into the prefetch sets, mask selects, ds_write_b128 -- is time the matrix pipe
+// idles (staging = 40 % of the kernel).  Here a chunk costs each wave ten DMA instructions and ~70 VALU of address masks:
+//   * an LDS-DMA writes lane l's 16 bytes to (M0 base + 16 l): the image must be lane-linear, so wgrad2's bank swizzle
+//     (64-byte halves of a pixel swapped when bit 1 of the pixel index is set) moves to the SOURCE side -- lane (pixel p,
+//     slot s) fetches channel unit s ^ 4*bit1(p).  Same involution on the read side as before, identical LDS contents.
+//   * zero padding / ragged tiles / chunks past the split's end: the lane's offset is replaced by one beyond the buffer
+//     descriptor's num_records; the out-of-range load returns 0 and the DMA writes that 0 (tools/probe_dma.hip).
+//   * the descriptor base is re-pointed at every chunk's top-left halo pixel (scalar ALU), so the per-lane offsets are
+//     chunk-invariant constants.
+//   * THREE LDS buffers (120 KB): the DMAs of chunk q+2 are issued during chunk q (HBM latency under load exceeds one
+//     chunk), `s_waitcnt vmcnt(10)` + one raw s_barrier per chunk hand chunk q+1 to the readers and free buffer q-1.
+// The input must be plain (no BatchNorm+ReLU on load): the training schedule materialises relu(bn(z)) once per layer on
+// the weight-gradient stream (bdn_bnrelu) instead of re-deriving it in each of the Cout/64 column-tile blocks.
+struct Wg6 {
+    static constexpr int PW = 18, PH = 10, STR = 128;
+    static constexpr int PATCH_BYTES = 6 * 32 * STR;             // 180 patch pixels padded to 192 (24 DMA pieces of 8 pixels)
+    static constexpr int DZ_BYTES = 128 * STR;                   // 16 DMA pieces
     static constexpr int BUF = PATCH_BYTES + DZ_BYTES;
-    static constexpr int SMEM = 2 * BUF;
+    static constexpr int NBUF = 3;
+    static constexpr int SMEM = NBUF * BUF;
+    static constexpr unsigned NUM_RECORDS = 0x40000000u, OOB = 0x80000000u;
 };
 
-template <bool USE_BN>
-__global__ __launch_bounds__(512, 1) void wgrad3_kernel(WgradArgs a) {
-    constexpr int PW = Wg3::PW, STR = Wg3::STR, DSTR = Wg3::DSTR, BUF = Wg3::BUF, PATCH_BYTES = Wg3::PATCH_BYTES;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+// one LDS-DMA piece: every lane's 16 bytes at (descriptor base + voff) -> LDS byte (lds_dst + 16 lane).  Inline asm on
+// purpose: hipcc's wait-count pass drains the VM queue (vmcnt(0)) before the next ds_read behind an LDS-DMA it can see,
+// which serialises the pipeline; this one is invisible to it and is waited for by hand (vmcnt(N) + barrier).  M0 (the
+// DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(u32x4_t rsrc, unsigned lds_dst, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ u32x4_t raw_rsrc(const void* base, unsigned num_records) {
+    const unsigned long long p_ = reinterpret_cast<unsigned long long>(base);
+    u32x4_t r = {(unsigned)p_, (unsigned)(p_ >> 32) & 0xffffu, num_records, 0x00020000u};   // stride 0, raw 32-bit dwords
+    return r;
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
+    constexpr int PW = Wg6::PW, STR = Wg6::STR, BUF = Wg6::BUF, PATCH_BYTES = Wg6::PATCH_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) of 128 x ci [wn*32,+32) of 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
     const int half = lane >> 5, l31 = lane & 31;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.n_cot * a.n_cit;                      // n_cot counts 128-wide tiles here
+    const int ntile = a.n_cot * a.n_cit;
     const int tile = logical % ntile, split = logical / ntile;
-    const int co0 = (tile / a.n_cit) * 128, ci0 = (tile % a.n_cit) * 64;
+    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
     const int Cin = a.C0 + a.C1;
 
-    const bf16s* src; int Csrc, cs;
-    if (ci0 < a.C0) { src = reinterpret_cast<const bf16s*>(a.in0); Csrc = a.C0; cs = ci0; }
-    else { src = reinterpret_cast<const bf16s*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
-    const bf16s* dzp = reinterpret_cast<const bf16s*>(a.dz);
+    const unsigned char* src; int Csrc, cs;
+    if (ci0 < a.C0) { src = reinterpret_cast<const unsigned char*>(a.in0); Csrc = a.C0; cs = ci0; }
+    else { src = reinterpret_cast<const unsigned char*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
+    const unsigned char* dzp = reinterpret_cast<const unsigned char*>(a.dz);
 
-    // ---- staging ownership.  Patch: thread = (pixel lane tid>>3 of 64, unit tid&7), units i = 0..2 at pixel + 64 i.
-    //      dz: thread = (pixel lane tid>>4 of 32, unit tid&15 of the 16 units of 128 channels), units i = 0..3 at pixel + 32 i.
-    const int u_pix = tid >> 3, sub_e = (tid & 7) * 8;
-    const unsigned wbase = u_pix * STR + (tid & 7) * 16;
-    const int d_pix = tid >> 4, dsub_e = (tid & 15) * 8;
-    const unsigned dbase = PATCH_BYTES + d_pix * DSTR + (tid & 15) * 16;
-    int pyx[3];
-    unsigned poff[3];
+    // ---- DMA ownership: wave w, piece i = LDS pixels 8w + 32i .. +7; lane = (pixel u_pix of the piece, 16-byte slot sub)
+    const int u_pix = wave * 8 + (lane >> 3), sub = lane & 7;
+    const int unit = sub ^ (((u_pix >> 1) & 1) << 2);           // source channel unit of this LDS slot (pieces keep bit 1 of the pixel)
+    int pyx[6];                                                // patch pixel: (y-1, x-1) relative to the tile origin
+    unsigned poff[6];                                          // its byte offset from the chunk's top-left halo pixel
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int pix = u_pix + 64 * i, yy = pix / PW, xx = pix % PW;
-        pyx[i] = pix < Wg3::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
-        poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub_e) * 2);
+    for (int i = 0; i < 6; i++) {
+        const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
+        pyx[i] = pix < Wg6::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
+        poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + unit * 8) * 2);
     }
-    const unsigned poff_c = (unsigned)(((a.W + 1) * Csrc + cs + sub_e) * 2);          // the tile's origin pixel: always inside
-    const int dpx = d_pix & 15, dpy0 = d_pix >> 4;             // dz units: tile pixel (dpy0 + 2 i, dpx)
-    const unsigned drow = (unsigned)(a.W * a.Cout * 2);
-    const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + dsub_e) * 2);
-    const unsigned doff_c = (unsigned)((co0 + dsub_e) * 2);
+    const int dpx = u_pix & 15, dpy0 = u_pix >> 4;             // dz pieces: tile pixel (dpy0 + 2 i, dpx)
+    const unsigned drow2 = (unsigned)(2 * a.W * a.Cout * 2);
+    const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + unit * 8) * 2);
+    const unsigned lds_piece0 = (unsigned)(wave * 8 * STR);     // + 32 i STR (+ PATCH_BYTES for dz) + buffer offset
 
     f32x16 acc[9];
 #pragma unroll
@@ -511,85 +530,51 @@ __global__ __launch_bounds__(512, 1) void wgrad3_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
-    uint4 pR[3], dR[4];                                        // the prefetch register set (patch part, dz part)
-    unsigned mP = 0, mD = 0;
-    int gP = 0, cur_grp = -1;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
-
     const int q_begin = split * a.per_split;
     const int q_end = min(a.n_mtiles, q_begin + a.per_split);
-    int lq = q_begin;                                          // load cursor: chunk index and its tile coordinates
+    int lq = q_begin;                                          // DMA cursor: chunk index and its tile coordinates
     int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
-    int lg = ln / a.imgs_per_group;
-    int lpix = 0, ly0 = 0, lx0 = 0;
-    bool llive = false;
+    // per-chunk state of the DMA issue (set by W6_BEGIN, used by the W6_P / W6_D pieces spread over the MFMA rows)
+    u32x4_t rs_p = {0, 0, 0, 0}, rs_d = {0, 0, 0, 0};
+    int cy0 = 0, cx0 = 0; bool clive = false;
+    unsigned cwb = 0;
+    const unsigned smem_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);   // LDS byte address
 
-    // patch part of the next chunk in sequence (advances the cursor; the dz part of the same chunk follows later)
-#define W3_LOAD_P()                                                                                      \
+#define W6_BEGIN(wb_)                                                                                    \
     {                                                                                                   \
-        llive = lq < q_end;                                                                             \
-        ly0 = lty * 8; lx0 = ltx * 16;                                                                  \
-        if (llive) { lpix = (ln * a.H + ly0) * a.W + lx0; gP = lg; }                                    \
-        const unsigned char* sp_ = reinterpret_cast<const unsigned char*>(src) + ((long)(lpix - a.W - 1) * Csrc) * 2; \
-        unsigned m_ = 0;                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                  \
-            const int y_ = ly0 + (pyx[i] >> 16), x_ = lx0 + (short)(pyx[i] & 0xffff);                   \
-            const bool ok_ = llive && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;     \
-            pR[i] = *reinterpret_cast<const uint4*>(sp_ + (ok_ ? poff[i] : poff_c));                    \
-            m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
-        }                                                                                               \
-        mP = m_;                                                                                        \
-        if (llive) {                                                                                    \
-            lq++;                                                                                       \
-            if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
-        }                                                                                               \
+        clive = lq < q_end; cy0 = lty * 8; cx0 = ltx * 16; cwb = (wb_);                                  \
+        const long pixbase_ = clive ? (long)(ln * a.H + cy0) * a.W + cx0 : 0;                           \
+        rs_p = raw_rsrc(src + (pixbase_ - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS);                        \
+        rs_d = raw_rsrc(dzp + pixbase_ * a.Cout * 2, Wg6::NUM_RECORDS);                                 \
+        if (clive) { lq++; if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; } } } \
     }
-#define W3_LOAD_D()                                                                                      \
+#define W6_P(i_)                                                                                         \
     {                                                                                                   \
-        const unsigned char* dp_ = reinterpret_cast<const unsigned char*>(dzp) + ((long)lpix * a.Cout) * 2; \
-        unsigned m_ = 0;                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
-            const bool ok_ = llive && (ly0 + dpy0 + 2 * i) < a.H && (lx0 + dpx) < a.W;                  \
-            dR[i] = *reinterpret_cast<const uint4*>(dp_ + (ok_ ? doff0 + (unsigned)(2 * i) * drow : doff_c)); \
-            m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
-        }                                                                                               \
-        mD = m_;                                                                                        \
+        const int y_ = cy0 + (pyx[i_] >> 16), x_ = cx0 + (short)(pyx[i_] & 0xffff);                     \
+        const bool ok_ = clive && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;         \
+        lds_dma16(rs_p, smem_base + cwb + lds_piece0 + (i_) * 32 * STR, ok_ ? poff[i_] : Wg6::OOB);      \
     }
-#define W3_GROUP(g_)                                                                                     \
-    if (USE_BN && (g_) != cur_grp) {                                                                    \
-        cur_grp = (g_);                                                                                 \
-        const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub_e;                              \
-        const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub_e;                              \
-        _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }                \
-    }
-#define W3_ST_P(i_, wb_)                                                                                 \
+#define W6_D(i_)                                                                                         \
     {                                                                                                   \
-        uint4 v_ = pR[i_];                                                                              \
-        if (USE_BN) v_ = bnrelu_unit<bf16s>(v_, sc, sh);                                                \
-        const bool ok_ = (mP >> (i_)) & 1u;                                                             \
-        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-        *reinterpret_cast<uint4*>((wb_) + wbase + (i_) * 64 * STR) = v_;                                \
-    }
-#define W3_ST_D(i_, wb_)                                                                                 \
-    {                                                                                                   \
-        uint4 v_ = dR[i_];                                                                              \
-        const bool ok_ = (mD >> (i_)) & 1u;                                                             \
-        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-        *reinterpret_cast<uint4*>((wb_) + dbase + (i_) * 32 * DSTR) = v_;                               \
+        const bool ok_ = clive && (cy0 + dpy0 + 2 * (i_)) < a.H && (cx0 + dpx) < a.W;                   \
+        lds_dma16(rs_d, smem_base + cwb + PATCH_BYTES + lds_piece0 + (i_) * 32 * STR,                   \
+                  ok_ ? doff0 + (unsigned)(i_) * drow2 : Wg6::OOB);                                      \
     }
 
+    // ---- MFMA operand addressing: identical to wgrad2 (same LDS image)
     const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int kpix = (lane & 15) >> 2;
-    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * DSTR + wm * 64 + chan_b;    // + ks*16*DSTR (+4*DSTR)
-    const unsigned b_base = (half * 8 + kpix) * STR + wn * 64 + chan_b;                   // + (pr*PW + c)*STR (+4*STR)
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;
+    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
+    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
+    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
+#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
     uint4 af[4], bq[2][3];
 #define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
-#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * DSTR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * DSTR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + b_base + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + b_base + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
 #define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
-#define W3_ROW(pr_, ...)                                                                                 \
+#define WG_ROW(pr_, STG_)                                                                                \
     {                                                                                                   \
         if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
         if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
@@ -597,58 +582,57 @@ __global__ __launch_bounds__(512, 1) void wgrad3_kernel(WgradArgs a) {
         if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) }                     \
         if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
         if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) }       \
-        __VA_ARGS__                                                                                     \
+        STG_                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                              \
     }
-    // one chunk: compute from buffer rb_; the register set (chunk q+1) goes into buffer wb_ and is refilled with chunk q+2
-#define W3_CHUNK(rb_, wb_)                                                                               \
-    {                                                                                                   \
-        const unsigned char* rb = (rb_);                                                                \
-        unsigned char* wb = (wb_);                                                                      \
-        W3_GROUP(gP)                                                                                    \
-        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)                        \
-        W3_ROW(0, )                                                                                     \
-        W3_ROW(1, W3_ST_P(0, wb))                                                                       \
-        W3_ROW(2, W3_ST_P(1, wb))                                                                       \
-        W3_ROW(3, W3_ST_P(2, wb))                                                                       \
-        W3_ROW(4, W3_LOAD_P())                                                                          \
-        W3_ROW(5, W3_ST_D(0, wb))                                                                       \
-        W3_ROW(6, W3_ST_D(1, wb))                                                                       \
-        W3_ROW(7, W3_ST_D(2, wb))                                                                       \
-        W3_ROW(8, W3_ST_D(3, wb))                                                                       \
-        W3_ROW(9, W3_LOAD_D())                                                                          \
-    }
 
-    unsigned char* buf0 = smem;
-    unsigned char* buf1 = smem + BUF;
     if (q_begin < q_end) {
-        W3_LOAD_P() W3_LOAD_D()
-        W3_GROUP(gP)
+        // prologue: chunks q_begin and q_begin + 1 on their way into buffers 0 and 1
+        W6_BEGIN(0)
 #pragma unroll
-        for (int i = 0; i < 3; i++) W3_ST_P(i, buf0)
+        for (int i = 0; i < 6; i++) W6_P(i)
 #pragma unroll
-        for (int i = 0; i < 4; i++) W3_ST_D(i, buf0)
-        W3_LOAD_P() W3_LOAD_D()
-        __syncthreads();
-        for (int q = q_begin; q < q_end; q += 2) {
-            W3_CHUNK(buf0, buf1)
-            __syncthreads();
-            W3_CHUNK(buf1, buf0)                              // an odd tail runs on an all-zero chunk (masks are clear past q_end)
-            __syncthreads();
+        for (int i = 0; i < 4; i++) W6_D(i)
+        W6_BEGIN(BUF)
+#pragma unroll
+        for (int i = 0; i < 6; i++) W6_P(i)
+#pragma unroll
+        for (int i = 0; i < 4; i++) W6_D(i)
+        unsigned cur = 0, nxt2 = 2 * BUF;                      // byte offsets of the buffer read now / filled for chunk q+2
+        for (int q = q_begin; q < q_end; q++) {
+            // chunk q has landed (this wave's ten older DMAs; chunk q+1's ten may still fly); after the barrier every wave's
+            // have, and nobody reads buffer (q-1) % 3 any more -- which is where chunk q+2 goes
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* rb = smem + cur;
+            W6_BEGIN(nxt2)
+            LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)
+            WG_ROW(0, W6_P(0))
+            WG_ROW(1, W6_P(1))
+            WG_ROW(2, W6_P(2))
+            WG_ROW(3, W6_P(3))
+            WG_ROW(4, W6_P(4))
+            WG_ROW(5, W6_P(5))
+            WG_ROW(6, W6_D(0))
+            WG_ROW(7, W6_D(1))
+            WG_ROW(8, W6_D(2))
+            WG_ROW(9, W6_D(3))
+            cur = cur == 2 * BUF ? 0 : cur + BUF;
+            nxt2 = nxt2 == 2 * BUF ? 0 : nxt2 + BUF;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the two trailing (all-zero) chunks: nothing may land after exit
     }
-#undef W3_LOAD_P
-#undef W3_LOAD_D
-#undef W3_GROUP
-#undef W3_ST_P
-#undef W3_ST_D
+#undef W6_BEGIN
+#undef W6_P
+#undef W6_D
 #undef TRP
 #undef LDA
 #undef LDB
+#undef B_BASE
 #undef WG_MMA
-#undef W3_ROW
-#undef W3_CHUNK
+#undef WG_ROW
 
+    // partial[split][tap][co][ci], as wgrad2
     const int ci = ci0 + wn * 32 + l31;
     if (ci < Cin) {
         const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
@@ -663,227 +647,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3_kernel(WgradArgs a) {
     }
 }
 
-template <bool USE_BN>
-static int launch_wgrad3(const WgradArgs& a, hipStream_t st) {
-    auto kern = wgrad3_kernel<USE_BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg3::SMEM);
-        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad3: hipFuncSetAttribute(%d): %s", Wg3::SMEM, hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(512), Wg3::SMEM, st, a);
-    BDN_CHECK_LAUNCH("wgrad3");
-    return BDN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// wgrad5: wgrad2 split by ROLE.  Per-row cycle stamps of wgrad2 (s_memtime around every patch row) show where its chunk
-// goes: a row of nine MFMAs is 288 cycles of matrix core, but the row that also issues the ten global loads takes 1250,
-// a row with two BatchNorm'd LDS stores 600, with two plain stores 430 -- a wave cannot issue MFMAs while it sits in a
-// vector-memory / LDS-write / VALU instruction, and with one wave per SIMD nobody else can either.  Here a block is
-// eight waves: waves 0-3 (one per SIMD) are CONSUMERS -- fragment reads and MFMAs only, wgrad2's row walk, 72 MFMAs per
-// chunk -- and waves 4-7 are PRODUCERS that own the whole staging of the next chunk (global loads two chunks ahead,
-// BatchNorm + ReLU, masks, LDS writes).  Same 64 x 64 x 9 tile, same 80 KB double buffer, same one barrier per chunk,
-// same partial-sum traffic; the consumer's accumulators and the producer's prefetch sets live in different waves, so
-// both fit the 256 registers that two waves per SIMD allow.
-template <bool USE_BN>
-__global__ __launch_bounds__(512, 1) void wgrad5_kernel(WgradArgs a) {
-    constexpr int PW = Wg2::PW, STR = Wg2::STR, BUF = Wg2::BUF, PATCH_BYTES = Wg2::PATCH_BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.n_cot * a.n_cit;
-    const int tile = logical % ntile, split = logical / ntile;
-    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
-    const int Cin = a.C0 + a.C1;
-    const int q_begin = split * a.per_split;
-    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
-    unsigned char* buf0 = smem;
-    unsigned char* buf1 = smem + BUF;
-    if (q_begin >= q_end) return;                              // (never: the plan leaves no empty split) -- uniform for the block
-
-    if (wave >= 4) {
-        // ================================================= producer: stage chunk q+1 while the consumers are in chunk q
-        const int tid = threadIdx.x & 255;
-        const bf16s* src; int Csrc, cs;
-        if (ci0 < a.C0) { src = reinterpret_cast<const bf16s*>(a.in0); Csrc = a.C0; cs = ci0; }
-        else { src = reinterpret_cast<const bf16s*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
-        const bf16s* dzp = reinterpret_cast<const bf16s*>(a.dz);
-        const int u_pix = tid >> 3, sub = tid & 7, sub_e = sub * 8;
-        const unsigned wbase = u_pix * STR + ((sub ^ (((u_pix >> 1) & 1) << 2)) * 16);
-        int pyx[6];
-        unsigned poff[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
-            pyx[i] = pix < Wg2::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (int)0xf0000000;   // never inside
-            poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub_e) * 2);
-        }
-        const int dpx = u_pix & 15, dpy0 = u_pix >> 4;
-        const unsigned poff_c = (unsigned)((((a.W + 1)) * Csrc + cs + sub_e) * 2);
-        const unsigned drow = (unsigned)(a.W * a.Cout * 2);
-        const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + sub_e) * 2);
-        const unsigned doff_c = (unsigned)((co0 + sub_e) * 2);
-        uint4 pA[6], dA[4], pB[6], dB[4];
-        unsigned mA = 0, mB = 0;
-        int gA = 0, gB = 0;
-        int cur_grp = -1;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
-        int lq = q_begin;
-        int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
-        int lg = ln / a.imgs_per_group;
-        int lpix = 0;
-#define WG_LOAD(P, D, M, G)                                                                              \
-        {                                                                                               \
-            const bool live_ = lq < q_end;                                                              \
-            const int y0_ = lty * 8, x0_ = ltx * 16;                                                    \
-            const int pixbase_ = live_ ? (ln * a.H + y0_) * a.W + x0_ : lpix;                           \
-            lpix = pixbase_;                                                                            \
-            const unsigned char* sp_ = reinterpret_cast<const unsigned char*>(src) + ((long)(pixbase_ - a.W - 1) * Csrc) * 2; \
-            const unsigned char* dp_ = reinterpret_cast<const unsigned char*>(dzp) + ((long)pixbase_ * a.Cout) * 2; \
-            if (live_) G = lg;                                                                          \
-            unsigned m_ = 0;                                                                            \
-            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
-                const int y_ = y0_ + (pyx[i] >> 16), x_ = x0_ + (short)(pyx[i] & 0xffff);               \
-                const bool ok_ = live_ && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W; \
-                P[i] = *reinterpret_cast<const uint4*>(sp_ + (ok_ ? poff[i] : poff_c));                 \
-                m_ |= (ok_ ? 1u : 0u) << i;                                                             \
-            }                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                              \
-                const bool ok_ = live_ && (y0_ + dpy0 + 2 * i) < a.H && (x0_ + dpx) < a.W;              \
-                D[i] = *reinterpret_cast<const uint4*>(dp_ + (ok_ ? doff0 + (unsigned)(2 * i) * drow : doff_c)); \
-                m_ |= (ok_ ? 1u : 0u) << (8 + i);                                                       \
-            }                                                                                           \
-            M = m_;                                                                                     \
-            if (live_) {                                                                                \
-                lq++;                                                                                   \
-                if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
-            }                                                                                           \
-        }
-#define WG_GROUP(g_)                                                                                     \
-        if (USE_BN && (g_) != cur_grp) {                                                                \
-            cur_grp = (g_);                                                                             \
-            const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub_e;                          \
-            const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub_e;                          \
-            _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }            \
-        }
-#define WG_STAGE(P, D, M, G, wb_)                                                                        \
-        {                                                                                               \
-            WG_GROUP(G)                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
-                uint4 v_ = P[i];                                                                        \
-                if (USE_BN) v_ = bnrelu_unit<bf16s>(v_, sc, sh);                                        \
-                const bool ok_ = ((M) >> i) & 1u;                                                       \
-                v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-                *reinterpret_cast<uint4*>((wb_) + wbase + i * 32 * STR) = v_;                           \
-            }                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                              \
-                uint4 v_ = D[i];                                                                        \
-                const bool ok_ = ((M) >> (8 + i)) & 1u;                                                 \
-                v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-                *reinterpret_cast<uint4*>((wb_) + PATCH_BYTES + wbase + i * 32 * STR) = v_;             \
-            }                                                                                           \
-        }
-        WG_LOAD(pA, dA, mA, gA)
-        WG_LOAD(pB, dB, mB, gB)
-        WG_STAGE(pA, dA, mA, gA, buf0)
-        WG_LOAD(pA, dA, mA, gA)
-        __syncthreads();
-        for (int q = q_begin; q < q_end; q += 2) {
-            WG_STAGE(pB, dB, mB, gB, buf1)
-            WG_LOAD(pB, dB, mB, gB)
-            __syncthreads();
-            WG_STAGE(pA, dA, mA, gA, buf0)                    // an odd tail stages an all-zero chunk (masks are clear past q_end)
-            WG_LOAD(pA, dA, mA, gA)
-            __syncthreads();
-        }
-#undef WG_LOAD
-#undef WG_GROUP
-#undef WG_STAGE
-        return;
-    }
-
-    // ===================================================== consumer: wgrad2's row walk, fragment reads and MFMAs only
-    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
-    const int half = lane >> 5, l31 = lane & 31;
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const int kpix = (lane & 15) >> 2;
-    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;
-    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
-    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
-    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
-#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
-    uint4 af[4], bq[2][3];
-#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
-#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
-#define WG_ROW(pr_)                                                                                      \
-    {                                                                                                   \
-        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
-        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) } \
-        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
-        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) } \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-    }
-#define WG_CHUNK(rb_)                                                                                    \
-    {                                                                                                   \
-        const unsigned char* rb = (rb_);                                                                \
-        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)                        \
-        WG_ROW(0) WG_ROW(1) WG_ROW(2) WG_ROW(3) WG_ROW(4) WG_ROW(5) WG_ROW(6) WG_ROW(7) WG_ROW(8) WG_ROW(9) \
-    }
-    __syncthreads();
-    for (int q = q_begin; q < q_end; q += 2) {
-        WG_CHUNK(buf0)
-        __syncthreads();
-        WG_CHUNK(buf1)
-        __syncthreads();
-    }
-#undef TRP
-#undef LDA
-#undef LDB
-#undef B_BASE
-#undef WG_MMA
-#undef WG_ROW
-#undef WG_CHUNK
-    const int ci = ci0 + wn * 32 + l31;
-    if (ci < Cin) {
-        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
-        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;                 // wave-uniform
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
-        }
-    }
-}
-
-template <bool USE_BN>
-static int launch_wgrad5(const WgradArgs& a, hipStream_t st) {
-    auto kern = wgrad5_kernel<USE_BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2::SMEM);
-        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad5: hipFuncSetAttribute(%d): %s", Wg2::SMEM, hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(512), Wg2::SMEM, st, a);
-    BDN_CHECK_LAUNCH("wgrad5");
+static int launch_wgrad6(const WgradArgs& a, hipStream_t st) {
+    auto kern = wgrad6_kernel;
+    BDN_SET_SMEM_ONCE(kern, Wg6::SMEM, "wgrad6");
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), Wg6::SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad6");
     return BDN_OK;
 }
 
@@ -1118,74 +886,73 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
     }
 }
 
+// ---- plan: tile geometry, split count, kernel variant.  A pure function of the shape and of the caller's `flags` word
+// (no process-wide tuning state: two threads may size and launch different plans concurrently).
+//   flags bits 0-1   phases (bdn_conv3x3_wgrad_ex)
+//   flags bits 8-11  kernel override: 0 = the library's choice, BDN_WG_SIMPLE / BDN_WG_PIPE / BDN_WG_DMA force one where the shape allows
+//   flags bits 16-28 target grid size of the GEMM (0 = default, one block per CU)
 #ifndef WG_SIMPLE_MULT
 #define WG_SIMPLE_MULT 2
 #endif
-static int g_wgrad_blocks = 256;      // bdn_set_tuning(BDN_TUNE_WGRAD_BLOCKS): target grid size of the weight-gradient GEMM
-static int g_wgrad_v3 = 0;           // bdn_set_tuning(BDN_TUNE_WGRAD_V3): 1 = eight-wave 128x64 kernel (wgrad3) where the shape allows it; 2 = the
-                                     // producer / consumer kernel (wgrad5) wherever wgrad2 would run.  Both are off by default: each is faster
-                                     // alone (wgrad5: -16..20 % on the layers without BatchNorm-on-load, bit-identical results) but fills the
-                                     // CU's register file, so the dz -> dgrad chain's kernels no longer run beside it (step +3 %).  wgrad3:
-                                     // -4 % on the weight gradients alone, but half the tiles means twice the splits and twice the partial-tile
-                                     // traffic, and the training step gets 1.9 % SLOWER (tools/ab_wgblocks.py 0,1 2)
-struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; bool v3; };
-static WgPlan wgrad_plan(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
+struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; int variant; };
+static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {
     WgPlan p;
+    const int Cin = C0 + C1;
     p.g = pick_tile(N, H, W, imgs_per_group);
-    // eight-wave 128x64-tile kernel: where the shape allows it and every block still gets at least 16 chunks (with
-    // fewer, the wider tile's prologue / epilogue outweighs its cheaper staging: d1b, d2b stay on wgrad2)
-    p.v3 = g_wgrad_v3 == 1 && Cout % 128 == 0 && Cin > 32 && Cin % 64 == 0 && p.g.TI == 1;
-    if (p.v3) {
-        const int t3 = (Cout / 128) * ((Cin + 63) / 64);
-        int s3 = (g_wgrad_blocks + t3 - 1) / t3;
-        if (s3 > p.g.n_mtiles) s3 = p.g.n_mtiles;
-        if (s3 < 1) s3 = 1;
-        if ((p.g.n_mtiles + s3 - 1) / s3 < 16) p.v3 = false;
-    }
-    p.n_cot = p.v3 ? Cout / 128 : Cout / 64;
+    p.n_cot = Cout / 64;
     p.n_cit = (Cin + 63) / 64;
+    p.ksplit = Cin <= 32;
     const int tiles = p.n_cot * p.n_cit;
-    // the simple kernel (first layer / 8x8 maps) has no software pipeline: it hides latency with a second block per CU
-    const bool simple = Cin <= 32 || p.g.TI != 1;
-    int S = ((simple ? WG_SIMPLE_MULT : 1) * g_wgrad_blocks + tiles - 1) / tiles;                      // ~256 blocks: the kernel runs beside the dgrad chain on a second stream, so
+    // the pipelined kernels cover full 64-channel input tiles on 8x16 spatial tiles whose tensors stay below 2^31 elements
+    const size_t cmax = (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1));
+    const bool pipe_ok = dtype == BDN_BF16 && !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 && C1 % 64 == 0 &&
+                         (size_t)N * H * W * cmax < ((size_t)1 << 31);
+    const int want = (flags >> 8) & 15;
+    // LDS-DMA kernel: plain inputs only (no BatchNorm+ReLU on load), and every image row / channel run must be addressable
+    // with 32-bit byte offsets from a chunk's halo origin (always true below 2^31 elements)
+    const bool dma_ok = pipe_ok && in_mode == BDN_IN_PLAIN;
+    p.variant = pipe_ok ? (dma_ok ? BDN_WG_DMA : BDN_WG_PIPE) : BDN_WG_SIMPLE;
+    if (want == BDN_WG_SIMPLE) p.variant = BDN_WG_SIMPLE;
+    if (want == BDN_WG_PIPE && pipe_ok) p.variant = BDN_WG_PIPE;
+    // the simple kernel (first layer / 8x8 maps / f32) has no software pipeline: it hides latency with a second block per CU
+    int blocks = (flags >> 16) & 0x1fff;
+    if (blocks == 0) blocks = 256;                          // ~one block per CU: the kernel runs beside the dgrad chain on a second stream, so
                                                             // a smaller partial-sum footprint beats more parallelism (A/B: 512 -> 256 = -2.7 % step)
+    int S = ((p.variant == BDN_WG_SIMPLE ? WG_SIMPLE_MULT : 1) * blocks + tiles - 1) / tiles;
     if (S > p.g.n_mtiles) S = p.g.n_mtiles;
     if (S < 1) S = 1;
     p.per_split = (p.g.n_mtiles + S - 1) / S;
     p.S = (p.g.n_mtiles + p.per_split - 1) / p.per_split;   // no empty splits
-    p.ksplit = Cin <= 32;
     return p;
 }
 
-extern "C" int bdn_set_tuning(int key, int value) {
-    if (key == BDN_TUNE_WGRAD_BLOCKS && value >= 1 && value <= 4096) { g_wgrad_blocks = value; return BDN_OK; }
-    if (key == BDN_TUNE_WGRAD_V3 && value >= 0 && value <= 2) { g_wgrad_v3 = value; return BDN_OK; }
-    BDN_FAIL(BDN_E_ARG, "set_tuning: unknown key %d or value %d out of range", key, value);
+extern "C" size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
+                                               int in_mode, int flags) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0 || imgs_per_group <= 0) return 0;
+    const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags);
+    return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * (C0 + C1) * sizeof(float);
 }
 
 extern "C" size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || imgs_per_group <= 0) return 0;
-    WgPlan p = wgrad_plan(N, H, W, Cout, Cin, imgs_per_group);
-    return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * Cin * sizeof(float);
+    // default flags, any dtype / source split / input mode: the largest plan (the simple kernel's, which both dtypes may take)
+    const size_t a = bdn_wgrad_workspace_bytes_ex(BDN_F32, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
+    const size_t b = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
+    return a > b ? a : b;
 }
 
 template <typename T, int TH, int TW, int TI, bool KSPLIT>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     using CF = WgCfg<T, TH, TW, TI>;
     auto kern = wgrad_kernel<T, TH, TW, TI, KSPLIT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-        if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", CF::SMEM, hipGetErrorString(e));
-        attr_set = true;
-    }
+    BDN_SET_SMEM_ONCE(kern, CF::SMEM, "wgrad");
     hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), CF::SMEM, st, a);
     BDN_CHECK_LAUNCH("wgrad");
     return BDN_OK;
 }
 
-// phases: bit 0 = the split-K GEMM (partial tiles into `partial`), bit 1 = the fixed-order reduction of the partial
-// tiles into dw_oihw.  bdn_conv3x3_wgrad runs both; a profiler that wants the GEMM's own duration calls them apart.
+// flags bits 0-1 = phases: bit 0 = the split-K GEMM (partial tiles into `partial`), bit 1 = the fixed-order reduction of the
+// partial tiles into dw_oihw.  bdn_conv3x3_wgrad runs both; a profiler that wants the GEMM's own duration calls them apart.
+// Higher bits: per-call plan overrides (wgrad_plan above); `partial` must then hold bdn_wgrad_workspace_bytes_ex(flags).
 extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
                                     const void* in0, int C0, const void* in1, int C1,
                                     int in_mode, const float* in_bn, int imgs_per_group,
@@ -1202,7 +969,8 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     if (in_mode == BDN_IN_BNRELU && (!in_bn || in1)) BDN_FAIL(BDN_E_ARG, "wgrad: BNRELU input needs in_bn and a single source");
     const int Cin = C0 + C1;
     if (Cin_real <= 0 || Cin_real > Cin) BDN_FAIL(BDN_E_SHAPE, "wgrad: Cin_real=%d out of range", Cin_real);
-    WgPlan p = wgrad_plan(N, H, W, Cout, Cin, imgs_per_group);
+    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
+    const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, phases);
     WgradArgs a;
     a.dz = dz; a.Cout = Cout; a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr; a.imgs_per_group = imgs_per_group;
@@ -1212,25 +980,15 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = BDN_OK;
     if (!(phases & 1)) {
-        if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
     } else if (dtype == BDN_BF16) {
-        // the pipelined kernel covers full 64-channel input tiles on 8x16 spatial tiles whose tensors stay below 2^31 elements
-        const bool v2 = !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 &&
-                        (size_t)N * H * W * (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1)) < ((size_t)1 << 31);
-#ifdef WG_NO_V2
-        const bool use_v2 = false;
-#else
-        const bool use_v2 = v2;
-#endif
-        if (use_v2 && p.v3 && C0 % 64 == 0) rc = a.in_bn ? launch_wgrad3<true>(a, st) : launch_wgrad3<false>(a, st);
-        else if (use_v2 && g_wgrad_v3 == 2) rc = a.in_bn ? launch_wgrad5<true>(a, st) : launch_wgrad5<false>(a, st);
-        else if (use_v2) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
+        if (p.variant == BDN_WG_DMA) rc = launch_wgrad6(a, st);
+        else if (p.variant == BDN_WG_PIPE) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
         else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);
-    } else if (dtype == BDN_F32) {
+    } else {
         if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1, true>(a, st) : launch_wgrad<float, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<float, 8, 16, 1, false>(a, st) : launch_wgrad<float, 8, 8, 2, false>(a, st);
-    } else BDN_FAIL(BDN_E_ARG, "wgrad: bad dtype %d", dtype);
+    }
     if (rc) return rc;
     if (phases & 2) {
         launch_wgrad_reduce(partial, dw_oihw, p.S * (p.ksplit ? 2 : 1), Cout, Cin, Cin_real, st);
@@ -1263,7 +1021,7 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
     if (!bdn_conv3x3_wgrad_bnbwd_supported(dtype, N, H, W, Cout, C0, imgs_per_group))
         BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: only bf16, Cout=64, C0=16, 8x16 tiles (got dtype %d Cout %d C0 %d)", dtype, Cout, C0);
     if (ldA < 64 || ldA % 8 || Cin_real <= 0 || Cin_real > 16) BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: bad ldA=%d / Cin_real=%d", ldA, Cin_real);
-    const WgPlan p = wgrad_plan(N, H, W, Cout, C0, imgs_per_group);
+    const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, 0, imgs_per_group, BDN_IN_PLAIN, 0);
     WgFirstArgs a;
     a.dA = (const bf16s*)dA; a.ldA = ldA; a.z = (const bf16s*)z; a.bn = bn; a.sums = sums; a.x = (const bf16s*)in0;
     a.partial = partial; a.N = N; a.H = H; a.W = W; a.imgs_per_group = imgs_per_group;
@@ -1277,12 +1035,8 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
     return BDN_OK;
 }
 
-// which kernel the GEMM phase runs (bench.py names its roofline line after it): 2 = wgrad2 pipeline, 1 = simple kernel
-extern "C" int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group) {
+// which kernel the GEMM phase runs for `flags` (bench.py names its roofline line after it): BDN_WG_SIMPLE / BDN_WG_PIPE / ...
+extern "C" int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || imgs_per_group <= 0) return 0;
-    const WgPlan p = wgrad_plan(N, H, W, Cout, C0 + C1, imgs_per_group);
-    const bool v2 = dtype == BDN_BF16 && !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 &&
-                    (size_t)N * H * W * (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1)) < ((size_t)1 << 31);
-    return v2 ? 2 : 1;
+    return wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags).variant;
 }
-

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import BDN_BF16, BDN_F32, IN_BNRELU, IN_PLAIN, call, ptr
+from ._lib import BDN_BF16, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_PIPE, call, ptr
 
 ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
@@ -128,9 +128,11 @@ class Workspace:
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
         self.n_wg1 = lib.bdn_wgrad_workspace_bytes(2 * B, H, W, L1.cout, L1.cin, B) // 4
+        self.n_act = max(self.z[L.name].numel() for L in eng.layers if L.name.endswith('a'))
         self._bwd = None
         self._outc_ws = None
         self.logits = None
+        self.leased = False        # True while a live autograd graph still needs this workspace's z / bn tables for its backward
 
     def outc_ws(self, eng):
         """Scratch of bdn_outc_bwd (per-block partial classifier gradients)."""
@@ -144,6 +146,7 @@ class Workspace:
             self._bwd = dict(bnb=torch.empty(self.n_bnb, dtype=torch.float32, device=device),
                              wg=torch.empty(self.n_wg, dtype=torch.float32, device=device),
                              wg1=torch.empty(self.n_wg1, dtype=torch.float32, device=device),
+                             act=torch.empty(self.n_act, dtype=self.x0.dtype, device=device),
                              sums=torch.empty(2 * 2 * 1024, dtype=torch.float32, device=device))
         return self._bwd
 
@@ -173,6 +176,8 @@ class BiDateEngine:
         self.fuse_head_bwd = True       # A/B switch: d4b's BatchNorm backward recomputes the classifier's data gradient from dlogits
         self.fuse_first_wgrad = True    # A/B switch: the first conv's BatchNorm backward inside its weight-gradient GEMM (bf16 only)
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
+        self.wgrad_dma = True           # A/B switch: relu(bn(z)) of the 'a' convs is materialised once on the weight-gradient stream and
+                                        # the following conv's weight-gradient GEMM takes the LDS-DMA kernel (plain operands only)
         self._diag_skip_wgrad = False
         self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
@@ -211,10 +216,17 @@ class BiDateEngine:
         return self._side[key]
 
     def workspace(self, B, H, W, device):
+        """A workspace of this shape that no live autograd graph owns (models/bidate_model.py leases the one its forward
+        filled until the graph dies): a second forward of the same shape before backward() -- two micro-batches summed into
+        one loss, a validation forward between forward and backward -- gets its own buffers instead of overwriting the
+        activations the first graph's backward will read.  The fused TrainStep never leases, so it keeps one workspace."""
         key = (B, H, W, str(device))
-        if key not in self._ws:
-            self._ws[key] = Workspace(self, B, H, W, device)
-        return self._ws[key]
+        pool = self._ws.setdefault(key, [])
+        for ws in pool:
+            if not ws.leased:
+                return ws
+        pool.append(Workspace(self, B, H, W, device))
+        return pool[-1]
 
     def _weights(self, L, P, need_wd):
         """Packed GEMM images of layer L (forward image, data-gradient image).  All 18 layers are (re)packed by
@@ -310,8 +322,12 @@ class BiDateEngine:
         dev = ws.x0.device
         st = _lib.stream_ptr()
         by = {L.name: L for L in self.layers}
-        if self._packed_valid and self._packed_versions != tuple(P[f'{L.conv}.weight']._version for L in self.layers):
-            self._packed_valid = False            # an optimizer touched the master weights
+        if self._packed_valid and (self._packed_versions != tuple(P[f'{L.conv}.weight']._version for L in self.layers) or
+                                   self._pack_desc[0] != tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)):
+            # an optimizer touched the master weights (version counters), or they were re-pointed at other storage.
+            # In-place writes through `p.data` (p.data.copy_(ema), p.data.clamp_()) bump NEITHER: call
+            # invalidate_weights() after such an update (BiDateNet.load_state_dict / _apply do it themselves).
+            self._packed_valid = False
         rb = reuse_eval_bn and not training
         # ---- shared encoder on both dates (2B images, 2 statistic groups)
         for k in range(1, 6):
@@ -382,12 +398,22 @@ class BiDateEngine:
         def wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, stp):
             """The weight-gradient GEMM and its reduction; with profiling on, the GEMM alone sits between two events
             recorded on the stream it is launched on."""
+            lib = _lib.load()
+            if mode == IN_BNRELU and self.wgrad_dma and \
+                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, 0) == WG_DMA:
+                # the DMA kernel's operands never pass through registers: write a = relu(bn(z)) once (instead of deriving it in
+                # each of the Cout/64 column-tile blocks of the GEMM) and hand the GEMM a plain tensor
+                act = sc['act'][:in0.numel()]
+                call('bdn_bnrelu', self.dt, ptr(in0), ptr(in_bn), ipg, ptr(act), n, hk, wk, c0, stp)
+                in0, mode, in_bn = act, IN_PLAIN, None
             args = (self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
             name = None
             if self.prof is not None:
-                v = _lib.load().bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg)
-                if v == 2:
+                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, 0)
+                if v == WG_DMA:
+                    name = 'wgrad6_kernel'
+                elif v == WG_PIPE:
                     name = f'wgrad2_kernel<{"true" if mode == IN_BNRELU else "false"}>'
                 else:
                     small = wk <= 8 and hk <= 8 and ipg % 2 == 0
@@ -538,6 +564,11 @@ class BiDateEngine:
                         call('bdn_conv3x3_wgrad_bnbwd', *wargs)
                 if zero_bias_grads:
                     grads[f'{La.conv}.bias'].zero_()
+                if side is not None:
+                    # this ready() may launch the LAST bucket's all-reduce, ordered behind the current (main) stream only;
+                    # the bucket also holds e1b / e2a weight gradients whose GEMM + reduction are still queued on the side
+                    # stream, so main joins side first (nothing of the chain is left to delay)
+                    main.wait_stream(side)
                 ready([f'{La.bn}.weight', f'{La.bn}.bias', f'{La.conv}.weight', f'{La.conv}.bias'])
                 keep += [dAb, dzb, dAa, dP]
                 dP = None

@@ -14,6 +14,18 @@ from .unet_parts import down, outconv, up, inconv
 from ..engine import BiDateEngine
 
 
+class _Lease:
+    """Marks an engine workspace as owned by one autograd graph; released when the graph (its ctx) is freed, i.e. after
+    backward() without retain_graph, or when the logits are dropped without a backward."""
+
+    def __init__(self, ws):
+        self.ws = ws
+        ws.leased = True
+
+    def __del__(self):
+        self.ws.leased = False
+
+
 class _BiDateFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward enqueues the fused HIP schedule, backward the
     hand-written backward schedule (no autograd tape through individual ops)."""
@@ -26,6 +38,8 @@ class _BiDateFunction(torch.autograd.Function):
         logits, ws = eng.forward(x_d1.detach(), x_d2.detach(), {k: v.detach() for k, v in P.items()}, training)
         ctx.module, ctx.ws, ctx.training = module, ws, training
         ctx.n_params = len(params)
+        if training and any(ctx.needs_input_grad):
+            ctx.lease = _Lease(ws)            # nobody else may run a forward on these buffers while this graph lives
         return logits
 
     @staticmethod
@@ -70,6 +84,20 @@ class BiDateNet(nn.Module):
     def forward(self, x_d1, x_d2):
         params = [p for _, p in self.named_parameters()]
         return _BiDateFunction.apply(self, x_d1, x_d2, *params)
+
+    # the packed bf16 / f32 GEMM images are derived from the master weights: anything that rewrites parameters behind
+    # autograd's version counters has to drop them
+    def load_state_dict(self, *args, **kw):
+        out = super().load_state_dict(*args, **kw)
+        if getattr(self, '_engine', None) is not None:
+            self._engine.invalidate_weights()
+        return out
+
+    def _apply(self, fn, *args, **kw):
+        out = super()._apply(fn, *args, **kw)
+        if getattr(self, '_engine', None) is not None:
+            self._engine.invalidate_weights()
+        return out
 
     # the engine and its workspaces are derived state: keep them out of pickles / deepcopies
     def __getstate__(self):

@@ -75,6 +75,46 @@ def validate(model, loader, dev, patch_size, alpha, beta):
     return get_mean_metrics(metrics)
 
 
+def train_epoch_autograd(model, criterion, optimizer, loader, dev, patch_size, world=1):
+    """The reference loop itself (train.py:83-101) for the criteria the fused step does not cover (dice / jaccard / focal):
+    autograd through the one-node BiDateNet function, torch.optim.SGD, gradients averaged over the ranks after backward."""
+    import torch.distributed as dist
+    from .utils.metrics import batch_prf_from_counts, confusion_counts
+    model.train()
+    metrics = initialize_metrics()
+    for b1, b2, labels in loader:
+        labels = labels.to(dev)
+        optimizer.zero_grad()
+        logits = model(b1.to(dev), b2.to(dev))
+        loss = criterion(logits, labels.long())
+        loss.backward()
+        if world > 1:
+            for p in model.parameters():
+                dist.all_reduce(p.grad)
+                p.grad /= world
+        optimizer.step()
+        model.engine().invalidate_weights()
+        c = confusion_counts(logits.detach(), labels).cpu()
+        metrics = set_metrics(metrics, loss.item(), 100.0 * int(c[3]) / (labels.shape[0] * patch_size ** 2), batch_prf_from_counts(c))
+    return get_mean_metrics(metrics)
+
+
+def save_if_better(model, mean_val_metrics, best_metrics, metadata, epoch, out_dir):
+    """train.py:207-227: when validation precision, recall OR F1 improved, write `checkpoint_epoch_N.pt` (the pickled
+    module, as the reference does with torch.save(model, ...)) and `metadata_epoch_N.json` (the run's metadata plus
+    `validation_metrics`).  The upload to the outputs store / comet is out of scope.  Returns the new best metrics."""
+    keys = ('cd_precisions', 'cd_recalls', 'cd_f1scores')
+    if not any(mean_val_metrics[k] > best_metrics[k] for k in keys):
+        return best_metrics
+    os.makedirs(out_dir, exist_ok=True)
+    metadata = dict(metadata)
+    metadata['validation_metrics'] = {k: float(v) for k, v in mean_val_metrics.items()}
+    with open(os.path.join(out_dir, f'metadata_epoch_{epoch}.json'), 'w') as fout:
+        json.dump(metadata, fout)
+    torch.save(model, os.path.join(out_dir, f'checkpoint_epoch_{epoch}.pt'))
+    return mean_val_metrics
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description='Training change detection network (HIP path)')
     for k, v in DEFAULTS.items():
@@ -85,7 +125,8 @@ def main(argv=None):
         else:
             ap.add_argument(f'--{k}', type=type(v), default=v)
     ap.add_argument('--synthetic', action='store_true', help='use fabric_amd.utils.dataloaders.synthetic_onera()')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--focal_gamma', type=float, default=None, help='required by --loss_function focal (utils/helpers.py:291)')
     ap.add_argument('--metadata', default=None, help="JSON in the reference's metadata.json schema (band_ids, band_means, "
                                                      "band_stds, ...): its entries become defaults like utils/parser.py:7-10")
     pre, _ = ap.parse_known_args(argv)
@@ -97,7 +138,22 @@ def main(argv=None):
     opt = ap.parse_args(argv)
     for k in ('band_ids', 'band_means', 'band_stds'):
         setattr(opt, k, meta.get(k))
+    if opt.loss_function not in ('tversky', 'dice', 'jaccard', 'focal'):
+        raise SystemExit(f'--loss_function {opt.loss_function}: the reference offers bce / focal / dice / jaccard / tversky '
+                         f"(utils/helpers.py:288-314); its bce branch cannot run on BiDateNet's logits and is not built")
+    if opt.loss_function == 'focal' and opt.focal_gamma is None:
+        raise SystemExit('--loss_function focal needs --focal_gamma')
+
+    # one process per GPU (launched by torch.distributed.run): RANK / LOCAL_RANK / WORLD_SIZE from the environment
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)                            # the library's stream / workspace helpers follow the current device
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
     scenes = None
     if opt.synthetic:
         data = synthetic_onera(n_cities=6, bands=13, size=(360, 360))
@@ -111,15 +167,30 @@ def main(argv=None):
         data = {c: {'images': d['images'].cpu().numpy(), 'labels': d['labels']} for c, d in scenes.items()}
         val_cities = [c for c in opt.validation_cities if c in data]
     train_loader, val_loader = make_loaders(data, val_cities, opt.patch_size, opt.stride // 2 if opt.synthetic else opt.stride,
-                                            opt.batch_size, opt.augmentation)
+                                            opt.batch_size, opt.augmentation, rank=rank, world_size=world)
     model = BiDateNet(len(opt.band_ids) if opt.band_ids else 13, 2, precision=opt.precision).to(dev)
-    step = TrainStep(model, lr=opt.learning_rate, tversky_alpha=opt.tversky_alpha, tversky_beta=opt.tversky_beta)
+    fused = opt.loss_function == 'tversky'
+    if fused:
+        step = TrainStep(model, lr=opt.learning_rate, tversky_alpha=opt.tversky_alpha, tversky_beta=opt.tversky_beta)
+    else:
+        from .utils.helpers import get_criterion
+        criterion = get_criterion(opt)
+        optimizer = torch.optim.SGD(model.parameters(), lr=opt.learning_rate)      # train.py:55
+        if world > 1:
+            for p in model.parameters():
+                dist.broadcast(p.data, src=0)
+    best = {'cd_f1scores': -1, 'cd_recalls': -1, 'cd_precisions': -1}              # train.py:62
+    run_meta = dict(meta, **{k: getattr(opt, k) for k in DEFAULTS}, precision=opt.precision, world_size=world)
     for epoch in range(opt.epochs):
-        tr = train_epoch(step, train_loader, dev, opt.patch_size)
+        if fused:
+            tr = train_epoch(step, train_loader, dev, opt.patch_size)
+        else:
+            tr = train_epoch_autograd(model, criterion, optimizer, train_loader, dev, opt.patch_size, world)
         va = validate(model, val_loader, dev, opt.patch_size, opt.tversky_alpha, opt.tversky_beta)
-        print(json.dumps({'epoch': epoch, **{'train_' + k: float(v) for k, v in tr.items()},
-                          **{'validate_' + k: float(v) for k, v in va.items()}}))
-        if scenes is not None:                                 # train.py:182-205: full validation images
+        if rank == 0:
+            print(json.dumps({'epoch': epoch, **{'train_' + k: float(v) for k, v in tr.items()},
+                              **{'validate_' + k: float(v) for k, v in va.items()}}), flush=True)
+        if scenes is not None and rank == 0:                   # train.py:182-205: full validation images
             from .utils import ingest
             from .utils.inference import predict_scene
             os.makedirs(opt.log_dir, exist_ok=True)
@@ -128,6 +199,10 @@ def main(argv=None):
                 st = scenes[city]['images']
                 mask = predict_scene(model, st[0], st[1], patch_size=opt.patch_size, batch_size=opt.batch_size)
                 ingest.write_png_gray(os.path.join(opt.log_dir, f'{city}_epoch_{epoch}.png'), (mask * 255).cpu().numpy())
+        if rank == 0:                                          # replica 0's BatchNorm buffers, like DataParallel
+            best = save_if_better(model, va, best, run_meta, epoch, opt.log_dir)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -56,7 +56,9 @@ class TrainStep:
         return self._P
 
     def step(self, x_d1, x_d2, labels):
-        """One optimisation step.  Returns the loss as a 0-dim device tensor (no sync).
+        """One optimisation step.  Returns the loss as a fresh 0-dim device tensor (no sync; safe to keep in a list like
+        the reference loop does with `cd_loss`).  `last_counts` / `last_logits` are persistent buffers that the NEXT step
+        overwrites: clone them if they have to outlive it.
 
         The step's dependency chain (forward, loss, dz chain, SGD) is enqueued on a HIGH-priority HIP stream; the
         weight-gradient GEMMs run beside it on a normal-priority stream (engine.backward), so the chain's kernels get
@@ -111,4 +113,4 @@ class TrainStep:
         eng.invalidate_weights()                              # packed bf16/f32 GEMM images are now stale
         self.last_counts = counts
         self.last_logits = logits
-        return loss
+        return loss.clone()

@@ -12,43 +12,59 @@ import numpy as np
 import torch.utils.data as data
 
 
+# The eight symmetries of a square patch as (transpose, reverse rows, reverse columns), applied in that order.
+# np.rot90(m, k) over (rows, cols) is entry k; the reference's two optional flips toggle the reversals.
+_ROT = ((False, False, False), (True, True, False), (False, True, True), (True, False, True))
+
+
+def _draw_symmetry():
+    """The augmentation draw of reference utils/dataloaders.py:154-163 -- randint(0, 3), then one random() per flip,
+    always three draws from the global `random` module in this order -- folded into one element of the dihedral group."""
+    k = random.randint(0, 3)
+    flip_rows = random.random() > 0.5
+    flip_cols = random.random() > 0.5
+    t, rr, rc = _ROT[k]
+    return t, rr ^ flip_rows, rc ^ flip_cols
+
+
+def _apply_symmetry(window, sym):
+    """`window`: array view whose LAST two axes are (rows, cols).  One strided view, no intermediate copies."""
+    t, rr, rc = sym
+    if t:
+        window = window.swapaxes(-2, -1)
+    return window[..., ::-1 if rr else 1, ::-1 if rc else 1]
+
+
 def onera_siamese_loader(dataset, city, x, y, size, aug):
-    """reference utils/dataloaders.py:148-165: crop [2,C,x:x+size,y:y+size] and the label window; optional
-    rot90(k in 0..3) / flip-H / flip-W drawn from the global `random` module in the reference's order."""
-    out_img = np.copy(dataset[city]['images'][:, :, x:x + size, y:y + size])
-    out_lbl = np.copy(dataset[city]['labels'][x:x + size, y:y + size])
-    if aug:
-        rot_deg = random.randint(0, 3)
-        out_img = np.rot90(out_img, rot_deg, [2, 3]).copy()
-        out_lbl = np.rot90(out_lbl, rot_deg, [0, 1]).copy()
-        if random.random() > 0.5:
-            out_img = np.flip(out_img, axis=2).copy()
-            out_lbl = np.flip(out_lbl, axis=0).copy()
-        if random.random() > 0.5:
-            out_img = np.flip(out_img, axis=3).copy()
-            out_lbl = np.flip(out_lbl, axis=1).copy()
-    return out_img[0], out_img[1], out_lbl
+    """Drop-in for reference utils/dataloaders.py:148-165: the [C,size,size] windows of both dates and the label window
+    at rows x.., columns y.., optionally under a random symmetry of the square (same draws, same result as the
+    reference's rot90 / flip chain; pinned by fixture G7).  Returns fresh contiguous arrays (img_d1, img_d2, label)."""
+    entry = dataset[city]
+    rows, cols = slice(x, x + size), slice(y, y + size)
+    sym = _draw_symmetry() if aug else (False, False, False)
+    pair = np.ascontiguousarray(_apply_symmetry(entry['images'][:, :, rows, cols], sym))
+    label = np.ascontiguousarray(_apply_symmetry(entry['labels'][rows, cols], sym))
+    return pair[0], pair[1], label
 
 
 class OneraPreloader(data.Dataset):
-    """reference utils/dataloaders.py:168-198.  `metadata` = list of [city, i, j]; shuffled in place at
-    construction like the reference (utils/dataloaders.py:171)."""
+    """Drop-in for reference utils/dataloaders.py:168-198: a map-style dataset over `metadata` = list of [city, i, j]
+    patch origins into the pre-loaded `full_load` dict.  The list is shuffled IN PLACE at construction with the global
+    `random` module, as the reference does (utils/dataloaders.py:171) -- callers that seed `random` get the same order."""
 
     def __init__(self, root, metadata, full_load, input_size, aug=False):
         random.shuffle(metadata)
-        self.full_load = full_load
-        self.root = root
-        self.imgs = metadata
+        self.root, self.full_load = root, full_load
+        self.imgs = metadata                                 # attribute names are part of the reference's surface
+        self.input_size, self.aug = input_size, aug
         self.loader = onera_siamese_loader
-        self.aug = aug
-        self.input_size = input_size
-
-    def __getitem__(self, index):
-        city, x, y = self.imgs[index]
-        return self.loader(self.full_load, city, x, y, self.input_size, self.aug)
 
     def __len__(self):
         return len(self.imgs)
+
+    def __getitem__(self, index):
+        city, i, j = self.imgs[index]
+        return self.loader(self.full_load, city, i, j, self.input_size, self.aug)
 
 
 def patch_origins(height, width, patch_size, stride):

@@ -142,6 +142,15 @@ class TverskyLoss(nn.Module):
         return self._holder.get('counts')
 
 
+def confusion_counts(logits, labels):
+    """int32[4] device tensor {TP, FP, FN, correct} of argmax(logits, 1) vs labels (what train.py:96-106 hands to sklearn),
+    for criteria that do not report it themselves: one pass of the overlap-loss kernel, loss and gradient discarded."""
+    holder = {}
+    with torch.no_grad():
+        _OverlapFunction.apply(logits.detach(), labels, 0.5, 0.5, 1e-7, holder)
+    return holder['counts']
+
+
 def batch_prf_from_counts(counts):
     """sklearn precision_recall_fscore_support(average='binary', pos_label=1) as called at reference
     train.py:103-106, from on-device counts; zero division -> 0 like sklearn's default."""

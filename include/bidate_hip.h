@@ -50,15 +50,6 @@ int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
  * { const float* w_oihw; void* wf; void* wd; int32 Cout, Cin, Cin_pad, reserved; } (40 bytes each). */
 int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stream);
 
-/* Tuning knobs (process-wide, not part of the numerical contract; results stay deterministic for a fixed setting).
- * BDN_TUNE_WGRAD_BLOCKS: target number of blocks of the weight-gradient GEMM (default 256 = one per CU); changes
- * bdn_wgrad_workspace_bytes, so set it before sizing workspaces. */
-#define BDN_TUNE_WGRAD_BLOCKS 1
-#define BDN_TUNE_WGRAD_V3 2       /* 1: eight-wave 128x64-tile weight-gradient kernel where the shape allows; 2: producer / consumer
-                                      kernel (four MFMA waves + four staging waves, results bit-identical to the default).  Both are
-                                      faster alone and slower inside the overlapped training step; default 0 */
-int bdn_set_tuning(int key, int value);
-
 /* ---- 3x3 convolution, stride 1, zero padding 1: nn.Conv2d(ci,co,3,padding=1), models/unet_parts.py:13,16 ----
  * Implicit GEMM on MFMA.  The A operand is gathered from in0 (channels [0,C0)) and optionally in1
  * (channels [C0,C0+C1), the never-materialised torch.cat of models/unet_parts.py:78).
@@ -89,21 +80,35 @@ int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad,
 
 /* ---- weight gradient of the same convolution (autograd of models/unet_parts.py:13,16) ----
  * dz: [N,H,W,Cout]; inputs as in bdn_conv3x3.  partial: workspace of bdn_wgrad_workspace_bytes().
- * dw_oihw: f32 [Cout,Cin_real,3,3] (overwritten; channels >= Cin_real of a padded input are dropped). */
+ * dw_oihw: f32 [Cout,Cin_real,3,3] (overwritten; channels >= Cin_real of a padded input are dropped).
+ * bdn_wgrad_workspace_bytes is pure: it covers every dtype / source split / input mode of the shape under default flags. */
 size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group);
 int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
                       const void* in0, int C0, const void* in1, int C1,
                       int in_mode, const float* in_bn, int imgs_per_group,
                       float* partial, float* dw_oihw, int Cin_real,
                       int N, int H, int W, void* stream);
-/* The same in two phases (phases bit 0: split-K GEMM into `partial`; bit 1: fixed-order reduction into dw_oihw), so that
- * a profiler can bracket the GEMM alone; and which GEMM kernel a shape gets (2 = software-pipelined wgrad2, 1 = simple). */
+/* The same with a per-call `flags` word (there is no process-wide tuning state):
+ *   bits 0-1   phases: bit 0 = split-K GEMM into `partial`, bit 1 = fixed-order reduction into dw_oihw (a profiler can
+ *              bracket the GEMM alone by issuing the phases apart);
+ *   bits 8-11  kernel override (0 = the library's choice): BDN_WG_SIMPLE, BDN_WG_PIPE, BDN_WG_DMA -- honoured where the
+ *              shape class allows it, ignored otherwise (ask bdn_conv3x3_wgrad_variant what a call will run);
+ *   bits 16-28 target number of blocks of the GEMM (0 = default 256, one per CU).
+ * With non-default flags `partial` must hold bdn_wgrad_workspace_bytes_ex(same arguments).  Results are deterministic
+ * for fixed flags; different plans differ only in the summation order of the partial tiles. */
+#define BDN_WG_SIMPLE 1      /* one-chunk-at-a-time kernel (any dtype, first layer, 8x8 maps) */
+#define BDN_WG_PIPE   2      /* software-pipelined bf16 kernel, operands staged through registers (BatchNorm+ReLU on load) */
+#define BDN_WG_DMA    3      /* bf16 kernel whose operands go HBM -> LDS by buffer_load ... lds (plain inputs only) */
+#define BDN_WG_FLAGS(phases, kernel, blocks) ((phases) | ((kernel) << 8) | ((blocks) << 16))
+size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
+                                    int in_mode, int flags);
 int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
                          const void* in0, int C0, const void* in1, int C1,
                          int in_mode, const float* in_bn, int imgs_per_group,
                          float* partial, float* dw_oihw, int Cin_real,
-                         int N, int H, int W, int phases, void* stream);
-int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group);
+                         int N, int H, int W, int flags, void* stream);
+int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
+                              int in_mode, int flags);
 /* Weight gradient of the FIRST convolution (inc.conv.conv.0, models/unet_parts.py:13 via unet_model.py inconv) with the
  * BatchNorm+ReLU backward of its own output (unet_parts.py:14-15) fused into the staging: the layer has no data gradient,
  * so dz = bn_bwd(dA, z) is never written -- the kernel reads dA [N,H,W,ldA>=64] and z [N,H,W,64], applies
@@ -155,6 +160,11 @@ int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const fl
 int bdn_bn_bwd_finalize(const float* bn, int G, int C, const float* partial, int rows_per_group, int raw_moment,
                         float* sums, float* dgamma, float* dbeta, void* scratch, void* stream);
 
+/* a = relu(z*scale + shift) written out (nn.BatchNorm2d + nn.ReLU, models/unet_parts.py:14-15): z, out [N,H,W,C]; bn [G][4][C].
+ * Rounded exactly like the on-load application inside bdn_conv3x3 / bdn_conv3x3_wgrad, whose BDN_WG_DMA kernel needs a
+ * plain operand. */
+int bdn_bnrelu(int dtype, const void* z, const float* bn, int imgs_per_group, void* out,
+               int N, int H, int W, int C, void* stream);
 /* ---- nn.MaxPool2d(2) on relu(bn(z)): models/unet_parts.py:40 (floor mode) ---- */
 int bdn_bnrelu_pool(int dtype, const void* z, const float* bn, int imgs_per_group,
                     void* out, int N, int H, int W, int C, void* stream);

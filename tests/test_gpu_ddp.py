@@ -1,12 +1,20 @@
 """-m gpu: the data-parallel step end to end on real kernels.  A gpurun box has ONE GPU, and RCCL refuses two
 ranks on one device, so the two ranks share cuda:0 and exchange gradients over gloo; everything else (sharded
 batch, local BatchNorm statistics, bucketed all-reduce launched from backward next to the wgrad stream, averaged
-SGD update) is the code path the 8-GPU RCCL run takes."""
+SGD update) is the code path the 8-GPU RCCL run takes.  With two or more GPUs visible the same worker also runs
+over RCCL (backend 'nccl'), one rank per device.
+
+Cases: the fp32 parity setting on 3 bands, and the DEFAULT bf16 setting on 13 bands -- the only configuration in
+which the first conv's weight gradient takes the fused path whose final bucket is released from the main stream
+(reference utils/helpers.py:333-335 is what this replaces).  The 'delay' variants park the weight-gradient stream
+behind a long sleep kernel before every step: a bucket launched without being ordered behind that stream would
+all-reduce stale gradients and the ranks would diverge."""
 import os
 import subprocess
 import sys
 
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -15,29 +23,44 @@ _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[3])
 rank, world = int(sys.argv[1]), int(sys.argv[2])
+precision, c, delay, backend = sys.argv[5], int(sys.argv[6]), sys.argv[7] == '1', sys.argv[8]
 os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[4]
-dist.init_process_group('gloo', rank=rank, world_size=world)
-from fabric_amd import BiDateNet
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+devid = rank if backend == 'nccl' else 0
+torch.cuda.set_device(devid)
+dist.init_process_group(backend, rank=rank, world_size=world,
+                        **({'device_id': torch.device('cuda', devid)} if backend == 'nccl' else {}))
+from fabric_amd import BiDateNet, _lib
 from fabric_amd.train_step import TrainStep
 from oracle import filler
-torch.cuda.set_device(0)
-c, b, s, lr = 3, 4, 32, 0.05
+b, s, lr = 4, 32, 0.05
 x1, x2, lbl = filler.make_inputs(b * world, c, s, seed=11)
 x1, x2, lbl = (torch.from_numpy(v).cuda() for v in (x1, x2, lbl))
 sl = slice(rank * b, (rank + 1) * b)                      # this rank's shard of the global batch
-model = filler.fill_module(BiDateNet(c, 2, precision='fp32')).cuda().train()
+model = filler.fill_module(BiDateNet(c, 2, precision=precision)).cuda().train()
 ts = TrainStep(model, lr=lr, n_buckets=3)
 assert ts.world == world
+eng = model.engine()
+if precision == 'bf16' and c == 13:
+    assert eng.fuse_first_wgrad and _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(eng.dt, 2 * b, s, s, 64, 16, b), \
+        'this case must exercise the fused first-layer weight gradient'
+    last = ts.bucketer.buckets[-1][2]
+    assert any(k.startswith('inc.conv.conv.3') for k in last) or any(k.startswith('down1') for k in last), last
+side = eng._side_stream(torch.device('cuda', devid))
 for _ in range(2):
+    if delay:                                             # the weight-gradient stream is busy for ~20 ms (at least ten steps) when backward starts
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(40_000_000)
     ts.step(x1[sl], x2[sl], lbl[sl])
 torch.cuda.synchronize()
 flat = ts.flat_params.cpu()
 # every rank must hold identical parameters after the averaged update
 others = [torch.empty_like(flat) for _ in range(world)]
-dist.all_gather(others, flat)
-assert all(torch.equal(o, flat) for o in others), 'ranks diverged'
-# single-process emulation of the same two DDP steps: per-shard gradients from identical weights, averaged
-models = [filler.fill_module(BiDateNet(c, 2, precision='fp32')).cuda().train() for _ in range(world)]
+dist.all_gather(others, flat.cuda() if backend == 'nccl' else flat)
+assert all(torch.equal(o.cpu(), flat) for o in others), 'ranks diverged'
+# single-process emulation of the same two DDP steps: per-shard gradients from identical weights, summed in rank
+# order and applied by the same SGD kernel (so the comparison is exact up to the all-reduce's summation order)
+models = [filler.fill_module(BiDateNet(c, 2, precision=precision)).cuda().train() for _ in range(world)]
 steps = [TrainStep(m, lr=0.0, distributed=False) for m in models]   # lr 0, no communication: local gradients only
 cur = steps[0].flat_params.clone()
 for _ in range(2):
@@ -47,7 +70,8 @@ for _ in range(2):
         st.model.engine().invalidate_weights()
         st.step(x1[r * b:(r + 1) * b], x2[r * b:(r + 1) * b], lbl[r * b:(r + 1) * b])
         g += st.flat_grads
-    cur = cur - lr * g / world
+    torch.cuda.synchronize()
+    _lib.call('bdn_sgd_step', cur.data_ptr(), g.data_ptr(), lr, 1.0 / world, cur.numel(), _lib.stream_ptr())
 torch.cuda.synchronize()
 err = (cur.cpu() - flat).abs().max().item()
 assert err < 5e-6, err
@@ -56,12 +80,34 @@ print('ok', rank, err)
 '''
 
 
-def test_two_ranks_on_one_gpu_match_the_averaged_gradient_update(tmp_path):
+def _run(tmp_path, precision, channels, delay, backend='gloo'):
     script = tmp_path / 'ddp_worker.py'
     script.write_text(_WORKER)
-    port = str(31000 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', ROOT, port],
+    port = str(31000 + (os.getpid() * 7 + channels + 2 * int(delay) + (5 if precision == 'bf16' else 0)) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', ROOT, port, precision, str(channels),
+                               '1' if delay else '0', backend],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=280)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
     assert all('ok' in o for o in outs)
+
+
+def test_two_ranks_on_one_gpu_match_the_averaged_gradient_update(tmp_path):
+    _run(tmp_path, 'fp32', 3, False)
+
+
+@pytest.mark.parametrize('delay', [False, True])
+def test_bf16_13band_two_ranks_fused_first_wgrad_path(tmp_path, delay):
+    """The configuration the 8-GPU run uses (bf16, 13 bands): rank-identical parameters equal to the shard average,
+    also when the weight-gradient stream lags far behind the main stream."""
+    _run(tmp_path, 'bf16', 13, delay)
+
+
+def test_fp32_two_ranks_delayed_side_stream(tmp_path):
+    _run(tmp_path, 'fp32', 3, True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank')
+@pytest.mark.parametrize('delay', [False, True])
+def test_bf16_13band_two_ranks_over_rccl(tmp_path, delay):
+    _run(tmp_path, 'bf16', 13, delay, backend='nccl')

@@ -232,6 +232,24 @@ def test_bnrelu_pool(prec, shape):
 
 
 @pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('shape', [(4, 16, 16, 64, 2), (2, 45, 22, 64, 1), (3, 7, 5, 512, 3), (2, 9, 9, 16, 1)])
+def test_bnrelu_materialised(prec, shape):
+    """bdn_bnrelu writes exactly the tensor the 3x3 consumers derive on load (models/unet_parts.py:14-15)."""
+    N, H, W, C, ipg = shape
+    dt, td = DT[prec]
+    z = rnd(prec, _rand((N, C, H, W), 141))
+    bn = bn_table(N // ipg, C, 142)
+    ref = bnrelu_ref(prec, z, bn, ipg)
+    out = torch.full((N, H, W, C), float('nan'), dtype=td, device='cuda')
+    z_d, bn_d = to_nhwc(prec, z), dev(bn)
+    _lib.call('bdn_bnrelu', dt, z_d.data_ptr(), bn_d.data_ptr(), ipg, out.data_ptr(), N, H, W, C, st())
+    torch.cuda.synchronize()
+    assert_close('bnrelu', from_nhwc(out), ref, 1e-6 if prec == 'fp32' else 8e-3)
+    with pytest.raises(RuntimeError):
+        _lib.call('bdn_bnrelu', dt, z_d.data_ptr(), bn_d.data_ptr(), ipg, out.data_ptr(), N, H, W, C + 1, st())
+
+
+@pytest.mark.parametrize('prec', PRECS)
 def test_fuse_product(prec):
     B, H, W, C = 3, 10, 12, 64
     dt, td = DT[prec]
@@ -667,69 +685,58 @@ def test_product_pool_equals_separate_kernels(prec, shape):
     assert torch.equal(f1, f2) and torch.equal(p1, p2)
 
 
-def test_wgrad_phases_variant_and_tuning_knob():
-    """bdn_conv3x3_wgrad_ex(phases 1 then 2) == bdn_conv3x3_wgrad; the grid-size knob changes the workspace, not the result
-    beyond the summation order of the partial tiles; bdn_conv3x3_wgrad_variant names the kernel family."""
+def test_wgrad_phases_variant_and_per_call_flags():
+    """bdn_conv3x3_wgrad_ex(phases 1 then 2) == bdn_conv3x3_wgrad; the per-call grid-size field changes the workspace, not the
+    result beyond the summation order of the partial tiles; bdn_conv3x3_wgrad_variant names the kernel family; there is no
+    process-wide tuning state (the sizing query is a pure function of its arguments)."""
+    from fabric_amd._lib import WG_PIPE, WG_SIMPLE, wg_flags
     lib = _lib.load()
     N, H, W, Cout, C0, ipg = 16, 32, 32, 128, 64, 8
     dt, td = DT['bf16']
     dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 91)))
     x = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 92)))
-    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg) == 2          # pipelined wgrad2
-    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, 16, 0, ipg) == 1          # narrow input: simple kernel
-    assert lib.bdn_conv3x3_wgrad_variant(dt, N, 8, 8, Cout, C0, 0, ipg) == 1          # 8x8 maps: simple kernel
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, 0) in (2, 3)   # a pipelined kernel
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_BNRELU, 0) == WG_PIPE  # BatchNorm on load: register staging
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, 16, 0, ipg, IN_PLAIN, 0) == WG_SIMPLE  # narrow input
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, 8, 8, Cout, C0, 0, ipg, IN_PLAIN, 0) == WG_SIMPLE  # 8x8 maps
+    assert lib.bdn_conv3x3_wgrad_variant(DT['fp32'][0], N, H, W, Cout, C0, 0, ipg, IN_PLAIN, 0) == WG_SIMPLE
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, wg_flags(kernel=WG_SIMPLE)) == WG_SIMPLE
+    default_bytes = lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg)
     res = {}
-    try:
-        for blocks in (256, 64):
-            _lib.call('bdn_set_tuning', 1, blocks)
-            part = torch.empty(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg) // 4, device='cuda')
-            a = torch.empty(Cout, C0, 3, 3, device='cuda')
-            b = torch.full_like(a, float('nan'))
-            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
-                      part.data_ptr(), a.data_ptr(), C0, N, H, W, st())
-            for ph in (1, 2):
-                _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
-                          part.data_ptr(), b.data_ptr(), C0, N, H, W, ph, st())
-            torch.cuda.synchronize()
-            assert torch.equal(a, b)
-            res[blocks] = (a.cpu(), part.numel())
-    finally:
-        _lib.call('bdn_set_tuning', 1, 256)
-    assert res[64][1] < res[256][1]
-    assert_close('dw across grid sizes', res[64][0], res[256][0], 1e-5)
+    for blocks in (0, 64):
+        fl = wg_flags(0, 0, blocks)
+        nbytes = lib.bdn_wgrad_workspace_bytes_ex(dt, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, fl)
+        part = torch.empty(nbytes // 4, device='cuda')
+        a = torch.empty(Cout, C0, 3, 3, device='cuda')
+        b = torch.full_like(a, float('nan'))
+        _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+                  part.data_ptr(), a.data_ptr(), C0, N, H, W, fl | 3, st())
+        for ph in (1, 2):
+            _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+                      part.data_ptr(), b.data_ptr(), C0, N, H, W, fl | ph, st())
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        res[blocks] = (a.cpu(), nbytes)
+    assert res[64][1] < res[0][1] <= default_bytes
+    assert lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg) == default_bytes        # nothing above changed what it answers
+    c = torch.empty(Cout, C0, 3, 3, device='cuda')
+    part = torch.empty(default_bytes // 4, device='cuda')
+    _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+              part.data_ptr(), c.data_ptr(), C0, N, H, W, st())
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), res[0][0])
+    assert_close('dw across grid sizes', res[64][0], res[0][0], 1e-5)
     with pytest.raises(RuntimeError):
-        _lib.call('bdn_set_tuning', 99, 1)
+        _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+                  part.data_ptr(), c.data_ptr(), C0, N, H, W, 0, st())
 
 
-def test_wgrad3_eight_wave_variant_matches_wgrad2():
-    """BDN_TUNE_WGRAD_V3: the 128x64-tile, eight-wave kernel gives wgrad2's result up to the summation order of the splits
-    (ragged map, BatchNorm'd input, two statistic groups)."""
-    lib = _lib.load()
-    N, H, W, Cout, C0, ipg = 8, 40, 50, 256, 128, 4
-    dt, td = DT['bf16']
-    dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 95)))
-    x = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 96)))
-    bn_d = dev(bn_table(N // ipg, C0, 97))
-    out = {}
-    try:
-        for v in (0, 1):
-            _lib.call('bdn_set_tuning', 2, v)
-            part = torch.empty(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg) // 4, device='cuda')
-            dw = torch.full((Cout, C0, 3, 3), float('nan'), device='cuda')
-            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x.data_ptr(), C0, None, 0, IN_BNRELU, bn_d.data_ptr(), ipg,
-                      part.data_ptr(), dw.data_ptr(), C0, N, H, W, st())
-            torch.cuda.synchronize()
-            out[v] = dw.cpu()
-    finally:
-        _lib.call('bdn_set_tuning', 2, 0)
-    assert torch.isfinite(out[1]).all()
-    assert_close('wgrad3 vs wgrad2', out[1], out[0], 2e-6)
-
-
-@pytest.mark.parametrize('mode', ['bnrelu', 'plain2'])
-def test_wgrad5_producer_consumer_variant_is_bit_identical_to_wgrad2(mode):
-    """BDN_TUNE_WGRAD_V3 = 2: the role-split kernel (waves 0-3 MFMA, waves 4-7 staging) keeps wgrad2's tile, split plan and
-    accumulation order, so its result is the same float for float (ragged map, two statistic groups / two concatenated sources)."""
+@pytest.mark.parametrize('mode', ['bnrelu', 'plain', 'plain2'])
+def test_wgrad_kernel_variants_agree(mode):
+    """Every weight-gradient kernel a shape may run gives the same dW up to the summation order of the partial tiles
+    (ragged map, two statistic groups / two concatenated sources); with the same split plan the pipelined kernels are
+    bit-identical to each other."""
+    from fabric_amd._lib import WG_DMA, WG_PIPE, WG_SIMPLE, wg_flags
     lib = _lib.load()
     N, H, W, Cout, ipg = 6, 37, 50, 128, 3
     dt, td = DT['bf16']
@@ -739,21 +746,24 @@ def test_wgrad5_producer_consumer_variant_is_bit_identical_to_wgrad2(mode):
         x0, x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 196))), None
         bn_d, in_mode = dev(bn_table(N // ipg, C0, 197)), IN_BNRELU
     else:
-        C0, C1 = 64, 64
+        C0, C1 = (64, 64) if mode == 'plain2' else (128, 0)
         x0 = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 196)))
-        x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C1, H, W), 198)))
-        bn_d, in_mode = None, 0
-    out = {}
-    try:
-        for v in (0, 2):
-            _lib.call('bdn_set_tuning', 2, v)
-            part = torch.empty(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0 + C1, ipg) // 4, device='cuda')
-            dw = torch.full((Cout, C0 + C1, 3, 3), float('nan'), device='cuda')
-            _lib.call('bdn_conv3x3_wgrad', dt, dz.data_ptr(), Cout, x0.data_ptr(), C0, x1.data_ptr() if x1 is not None else None, C1,
-                      in_mode, bn_d.data_ptr() if bn_d is not None else None, ipg, part.data_ptr(), dw.data_ptr(), C0 + C1, N, H, W, st())
-            torch.cuda.synchronize()
-            out[v] = dw.cpu()
-    finally:
-        _lib.call('bdn_set_tuning', 2, 0)
-    assert torch.isfinite(out[2]).all()
-    assert torch.equal(out[2], out[0])
+        x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C1, H, W), 198))) if C1 else None
+        bn_d, in_mode = None, IN_PLAIN
+    out, ran = {}, {}
+    for v in (WG_SIMPLE, WG_PIPE, WG_DMA):
+        fl = wg_flags(3, v, 0)
+        ran[v] = lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, C1, ipg, in_mode, fl)
+        part = torch.empty(lib.bdn_wgrad_workspace_bytes_ex(dt, N, H, W, Cout, C0, C1, ipg, in_mode, fl) // 4, device='cuda')
+        dw = torch.full((Cout, C0 + C1, 3, 3), float('nan'), device='cuda')
+        _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x0.data_ptr(), C0, x1.data_ptr() if x1 is not None else None, C1,
+                  in_mode, bn_d.data_ptr() if bn_d is not None else None, ipg, part.data_ptr(), dw.data_ptr(), C0 + C1, N, H, W, fl, st())
+        torch.cuda.synchronize()
+        out[v] = dw.cpu()
+        assert torch.isfinite(out[v]).all()
+    assert ran[WG_SIMPLE] == WG_SIMPLE and ran[WG_PIPE] == WG_PIPE
+    assert_close('pipelined vs simple', out[WG_PIPE], out[WG_SIMPLE], 2e-6)
+    if ran[WG_DMA] == WG_DMA:
+        assert torch.equal(out[WG_DMA], out[WG_PIPE])
+    else:
+        assert mode == 'bnrelu'                              # BatchNorm on load needs the register-staged kernel

@@ -158,6 +158,54 @@ def test_first_layer_fused_weight_gradient_equals_two_kernel_path(golden_dir, na
             assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
+def test_dma_weight_gradient_switch_leaves_every_gradient_unchanged(golden_dir, name):
+    """engine.wgrad_dma (bf16): relu(bn(z)) materialised once + the LDS-DMA weight-gradient kernel instead of BatchNorm on
+    load inside the register-staged kernel -- same operands, same split plan, same accumulation order: bit-equal gradients."""
+    g, c, x1, x2, lbl = _load(golden_dir, name)
+    grads = {}
+    for dma in (False, True):
+        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
+        model.engine().wgrad_dma = dma
+        _tversky_torch(model(x1, x2), lbl).backward()
+        torch.cuda.synchronize()
+        grads[dma] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, prec):
+    """Plain autograd usage the reference supports: two micro-batches (and an eval forward in between) before one backward.
+    Each live graph owns its workspace, so the summed loss gives the sum of the separately computed gradients."""
+    g, c, x1, x2, lbl = _load(golden_dir, 'g1_c3_b4_s32')
+    y1, y2, lb2 = x2.flip(0).contiguous(), x1.flip(0).contiguous(), lbl.flip(0).contiguous()
+    sep = []
+    for a, b, l in ((x1, x2, lbl), (y1, y2, lb2)):
+        model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda().train()
+        _tversky_torch(model(a, b), l).backward()
+        sep.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda().train()
+    la = _tversky_torch(model(x1, x2), lbl)
+    model.eval()
+    with torch.no_grad():
+        model(y1, y2)                                   # a validation forward of the same shape between forward and backward
+    model.train()
+    lb = _tversky_torch(model(y1, y2), lb2)
+    assert len(model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device))]) == 2
+    (la + lb).backward()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        want = sep[0][k] + sep[1][k]
+        if k.endswith('running_mean') or 'num_batches' in k:
+            continue
+        assert (p.grad - want).abs().max() <= 1e-5 * want.abs().max() + 1e-9, k
+    del la, lb
+    # the graphs are gone: their workspaces are free again and the next forward reuses the first one
+    ws_pool = model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device))]
+    assert not any(w.leased for w in ws_pool)
+
+
 @pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90'])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_eval_mode_matches_reference(golden_dir, name, prec):
