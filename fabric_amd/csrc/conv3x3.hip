@@ -22,6 +22,7 @@
 
 struct ConvArgs {
     const void* in0; const void* in1; int C0, C1;
+    int ld0, ld1;                // pixel strides of in0 / in1 in elements (= C0 / C1 unless the source is a channel window of a wider tensor)
     const float* in_bn;          // [G][4][C0] or null
     int imgs_per_group;
     const void* w;               // fragment-ordered filter image (common.hpp: wfrag_index)
@@ -53,10 +54,13 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool BF = true>
+// TO: element type of the OUTPUT tensor (and of bs_z).  TO = T except in the bf16x3 setting, whose operands are bf16 hi/lo
+// splits of float32 tensors and whose outputs are float32.
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool BF = true, typename TO = T>
 struct ConvCfg {
     using TL = Tile<TH, TW, TI>;
     static constexpr int ES = sizeof(T);
+    static constexpr int OES = sizeof(TO);
     static constexpr int EPU = 16 / ES;
     static constexpr int CK = CKB / ES;
     static constexpr int UPP = CKB / 16;
@@ -76,7 +80,7 @@ struct ConvCfg {
     static constexpr int PATCH_ROWS = (BF && ROWS_ALLOC > TI * TL::PH) ? ROWS_ALLOC : TI * TL::PH;   // BF: branch-free staging
     static constexpr int PATCH_BYTES = PATCH_ROWS * ROWP;
     static constexpr int PBUF = (2 * PATCH_BYTES <= 64 * 1024) ? 2 : 1;   // double-buffer when two blocks still fit a CU
-    static constexpr int OSTR = BN * ES + 16;
+    static constexpr int OSTR = BN * OES + 16;
     static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
     static constexpr int MAIN_BYTES = PBUF * PATCH_BYTES;
     static constexpr int EPI_BYTES = BM * OSTR + 4 * BN * 2 * 4;
@@ -93,11 +97,11 @@ struct ConvCfg {
 // ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
-__global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
-    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE>;
+__global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
     constexpr int EPU = CF::EPU, UPP = CF::UPP, NPU = CF::NPU, CK = CF::CK, PBUF = CF::PBUF;
@@ -153,8 +157,8 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
 #define LOAD_PATCH(c0_)                                                                                  \
     {                                                                                                   \
         const T* src_; int cs_, Cs_;                                                                    \
-        if ((c0_) < a.C0) { src_ = reinterpret_cast<const T*>(a.in0); Cs_ = a.C0; cs_ = (c0_); }        \
-        else { src_ = reinterpret_cast<const T*>(a.in1); Cs_ = a.C1; cs_ = (c0_) - a.C0; }              \
+        if ((c0_) < a.C0) { src_ = reinterpret_cast<const T*>(a.in0); Cs_ = a.ld0; cs_ = (c0_); }       \
+        else { src_ = reinterpret_cast<const T*>(a.in1); Cs_ = a.ld1; cs_ = (c0_) - a.C0; }             \
         _Pragma("unroll") for (int i = 0; i < NPU; i++)       /* padding units read pixel 0 and are zeroed at the store */ \
             if (BRANCHFREE || p_pix[i] >= 0)                                                            \
                 preg[i] = *reinterpret_cast<const uint4*>(src_ + (size_t)(p_pix[i] >= 0 ? p_pix[i] : 0) * Cs_ + cs_ + p_sub); \
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
 #define EPI_PASS(STATS_, RAGGED_)                                                                         \
     _Pragma("unroll") for (int nj = 0; nj < NJ; nj++) {                                                   \
         const int col = (wn * NJ + nj) * 32 + l31;                                                       \
-        unsigned char* ob_ = otile + (wm * MI * 32 + 4 * half) * CF::OSTR + col * CF::ES;                \
+        unsigned char* ob_ = otile + (wm * MI * 32 + 4 * half) * CF::OSTR + col * CF::OES;               \
         const float bias = (STATS_) && a.bias ? a.bias[col0 + col] : 0.f;                                \
         float s = 0.f, q = 0.f;                                                                          \
         _Pragma("unroll") for (int mi = 0; mi < MI; mi++) {                                               \
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
                     }                                                                                    \
                     if (valid) { s += v; q = fmaf(v, v, q); }                                            \
                 }                                                                                        \
-                *reinterpret_cast<T*>(ob_ + srel_ * CF::OSTR) = from_f<T>(v);                            \
+                *reinterpret_cast<TO*>(ob_ + srel_ * CF::OSTR) = from_f<TO>(v);                          \
             }                                                                                            \
         }                                                                                                \
         if (STATS_) {                                                                                    \
@@ -346,20 +350,21 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
         a.stats_partial[((size_t)mtile * 2 + 0) * a.Cout + col0 + tid] = s;
         a.stats_partial[((size_t)mtile * 2 + 1) * a.Cout + col0 + tid] = q;
     }
-    constexpr int UPR = BN * CF::ES / 16;                    // 16-byte units per output pixel row
+    constexpr int UPR = BN * CF::OES / 16;                   // 16-byte units per output pixel row
+    constexpr int OEPU = 16 / CF::OES;                       // output elements per 16-byte unit
     static_assert(256 % UPR == 0 && UPR <= 64, "a thread keeps one channel unit through the copy-out loop");
-    T* outp = reinterpret_cast<T*>(a.out);
+    TO* outp = reinterpret_cast<TO*>(a.out);
     const bool bs = a.bs_z != nullptr;                       // block-uniform
-    const T* bsz = reinterpret_cast<const T*>(a.bs_z);
-    const int bsub = (tid % UPR) * EPU;                      // this thread's channels inside the block's column tile
-    float bs0[EPU], bs1[EPU], bsc[EPU], bsh[EPU];
+    const TO* bsz = reinterpret_cast<const TO*>(a.bs_z);
+    const int bsub = (tid % UPR) * OEPU;                     // this thread's channels inside the block's column tile
+    float bs0[OEPU], bs1[OEPU], bsc[OEPU], bsh[OEPU];
 #pragma unroll
-    for (int i = 0; i < EPU; i++) { bs0[i] = 0.f; bs1[i] = 0.f; bsc[i] = 0.f; bsh[i] = 0.f; }
+    for (int i = 0; i < OEPU; i++) { bs0[i] = 0.f; bs1[i] = 0.f; bsc[i] = 0.f; bsh[i] = 0.f; }
     if (bs) {
         const float* ps = bn_row(a.bs_bn, grp, 2, a.Cout) + col0 + bsub;
         const float* ph = bn_row(a.bs_bn, grp, 3, a.Cout) + col0 + bsub;
 #pragma unroll
-        for (int i = 0; i < EPU; i++) { bsc[i] = ps[i]; bsh[i] = ph[i]; }
+        for (int i = 0; i < OEPU; i++) { bsc[i] = ps[i]; bsh[i] = ph[i]; }
     }
     for (int u = tid; u < CF::BM * UPR; u += 256) {
         const int slot = u / UPR, sub = u % UPR;
@@ -367,14 +372,14 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
         const int n = n0 + ti, y = y0 + py, x = x0 + px;
         if (n < a.N && y < a.H && x < a.W) {
             uint4 v = *reinterpret_cast<const uint4*>(otile + slot * CF::OSTR + sub * 16);
-            const size_t o = ((size_t)(n * a.H + y) * a.W + x) * a.Cout + col0 + sub * EPU;
+            const size_t o = ((size_t)(n * a.H + y) * a.W + x) * a.Cout + col0 + sub * OEPU;
             *reinterpret_cast<uint4*>(outp + o) = v;
             if (bs) {                                        // the stored (rounded) gradient is what BatchNorm backward sees
-                float fg[EPU], fz[EPU];
-                Unit<T>::unpack(v, fg);
-                Unit<T>::unpack(*reinterpret_cast<const uint4*>(bsz + o), fz);
+                float fg[OEPU], fz[OEPU];
+                Unit<TO>::unpack(v, fg);
+                Unit<TO>::unpack(*reinterpret_cast<const uint4*>(bsz + o), fz);
 #pragma unroll
-                for (int i = 0; i < EPU; i++) {
+                for (int i = 0; i < OEPU; i++) {
                     const float g = fmaf(fz[i], bsc[i], bsh[i]) > 0.f ? fg[i] : 0.f;
                     bs0[i] += g; bs1[i] = fmaf(g, fz[i], bs1[i]);
                 }
@@ -385,15 +390,15 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
         // lanes tid, tid+UPR, ... of a wave hold the same channels: butterfly over those lane bits, then the four
         // waves meet in LDS (fixed order -> deterministic)
 #pragma unroll
-        for (int i = 0; i < EPU; i++) {
+        for (int i = 0; i < OEPU; i++) {
 #pragma unroll
             for (int m = UPR; m < 64; m <<= 1) { bs0[i] += __shfl_xor(bs0[i], m); bs1[i] += __shfl_xor(bs1[i], m); }
         }
         if (lane < UPR) {
 #pragma unroll
-            for (int i = 0; i < EPU; i++) {
-                red[((wave * BN) + lane * EPU + i) * 2] = bs0[i];
-                red[((wave * BN) + lane * EPU + i) * 2 + 1] = bs1[i];
+            for (int i = 0; i < OEPU; i++) {
+                red[((wave * BN) + lane * OEPU + i) * 2] = bs0[i];
+                red[((wave * BN) + lane * OEPU + i) * 2 + 1] = bs1[i];
             }
         }
         __syncthreads();
@@ -412,15 +417,15 @@ __global__ __launch_bounds__(256, ((ONE && BN == 64) || (BN == 64 && TH == 8)) ?
 static thread_local bool g_conv_query = false;
 static thread_local char g_conv_variant[160];
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
-    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE>;
+    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     if (g_conv_query) {
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s>",
-                 sizeof(T) == 2 ? "bf16" : "f32", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false");
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s%s>",
+                 sizeof(T) == 2 ? "bf16" : "f32", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false", sizeof(TO) != sizeof(T) ? ",f32out" : "");
         return BDN_OK;
     }
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE>;
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO>;
     BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
@@ -477,6 +482,16 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     return launch_conv<T, CKB, 8, 8, 2, 64, 2, 2>(a, g.n_mtiles, st);
 }
 
+// bf16x3 setting: same tile geometry as the plan above (the caller sizes the statistics buffer from it), 64-wide column tiles,
+// float32 outputs; the reduction runs over 3*Cin channels (hi|lo of the split operand, then its hi part again).
+template <int CKB>
+static int dispatch_conv_x3(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+    const TileGeom& g = p.g;
+    if (g.TH == 16) return launch_conv<bf16s, CKB, 16, 16, 1, 64, 4, 1, false, float>(a, g.n_mtiles, st);
+    if (g.TI == 1) return launch_conv<bf16s, CKB, 8, 16, 1, 64, 2, 2, false, float>(a, g.n_mtiles, st);
+    return launch_conv<bf16s, CKB, 8, 8, 2, 64, 2, 2, false, float>(a, g.n_mtiles, st);
+}
+
 extern "C" int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || imgs_per_group <= 0) return 0;
     return conv_plan(N, H, W, Cout, imgs_per_group).g.n_mtiles;
@@ -497,7 +512,14 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     if (in_mode != BDN_IN_BNRELU && in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3x3: bad in_mode %d", in_mode);
     if (in_mode == BDN_IN_BNRELU && in1) BDN_FAIL(BDN_E_ARG, "conv3x3: two-source input must be plain");
     ConvArgs a;
-    a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
+    a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ld0 = C0; a.ld1 = C1;
+    if (dtype == BDN_BF16X3) {
+        // in0 is the split operand of bdn_split_pack: [N,H,W,2*C0] bf16 = hi(C0) | lo(C0).  K = [hi | lo | hi] against the
+        // packed filter image [w_hi | w_hi | w_lo]: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo accumulate in the same f32 MFMA tile.
+        if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3x3(bf16x3): one split-packed, plain operand (bdn_split_pack does cat / BatchNorm+ReLU)");
+        if (C0 % 16) BDN_FAIL(BDN_E_SHAPE, "conv3x3(bf16x3): C0=%d must be a multiple of 16", C0);
+        a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0;
+    }
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
     a.bs_z = bs_z; a.bs_bn = bs_bn;
@@ -514,6 +536,9 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
         if (C0 % 32 == 0 && C1 % 32 == 0) return dispatch_conv<float, 128>(a, g, st);
         if (C0 % 16 == 0 && C1 % 16 == 0) return dispatch_conv<float, 64>(a, g, st);
         BDN_FAIL(BDN_E_SHAPE, "conv3x3(f32): C0=%d C1=%d must be multiples of 16", C0, C1);
+    } else if (dtype == BDN_BF16X3) {
+        if (a.C1 % 64 == 0) return dispatch_conv_x3<128>(a, g, st);
+        return dispatch_conv_x3<32>(a, g, st);
     }
     BDN_FAIL(BDN_E_ARG, "conv3x3: bad dtype %d", dtype);
 }

@@ -467,8 +467,6 @@ struct Wg6 {
     static constexpr int PATCH_BYTES = 6 * 32 * STR;             // 180 patch pixels padded to 192 (24 DMA pieces of 8 pixels)
     static constexpr int DZ_BYTES = 128 * STR;                   // 16 DMA pieces
     static constexpr int BUF = PATCH_BYTES + DZ_BYTES;
-    static constexpr int NBUF = 3;
-    static constexpr int SMEM = NBUF * BUF;
     static constexpr unsigned NUM_RECORDS = 0x40000000u, OOB = 0x80000000u;
 };
 
@@ -488,6 +486,10 @@ __device__ __forceinline__ u32x4_t raw_rsrc(const void* base, unsigned num_recor
     return r;
 }
 
+// NBUF = 3: chunk q+2 is fetched during chunk q (120 KB of LDS: the kernel owns its CU).  NBUF = 2: chunk q+1 during chunk q, all
+// ten pieces issued in the first five rows (80 KB and 224 registers per lane: a block of the data-gradient / forward convolution
+// -- 55-61 KB, <= 256 registers -- fits on the same CU, so the two MFMA kernels of the two streams share the matrix pipe).
+template <int NBUF>
 __global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
     constexpr int PW = Wg6::PW, STR = Wg6::STR, BUF = Wg6::BUF, PATCH_BYTES = Wg6::PATCH_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -587,40 +589,56 @@ __global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
     }
 
     if (q_begin < q_end) {
-        // prologue: chunks q_begin and q_begin + 1 on their way into buffers 0 and 1
+        // prologue: chunk q_begin (and, three buffers, q_begin + 1) on their way into buffers 0 (and 1)
         W6_BEGIN(0)
 #pragma unroll
         for (int i = 0; i < 6; i++) W6_P(i)
 #pragma unroll
         for (int i = 0; i < 4; i++) W6_D(i)
-        W6_BEGIN(BUF)
+        if constexpr (NBUF == 3) {
+            W6_BEGIN(BUF)
 #pragma unroll
-        for (int i = 0; i < 6; i++) W6_P(i)
+            for (int i = 0; i < 6; i++) W6_P(i)
 #pragma unroll
-        for (int i = 0; i < 4; i++) W6_D(i)
-        unsigned cur = 0, nxt2 = 2 * BUF;                      // byte offsets of the buffer read now / filled for chunk q+2
+            for (int i = 0; i < 4; i++) W6_D(i)
+        }
+        unsigned cur = 0, nxt = (NBUF - 1) * BUF;              // byte offsets of the buffer read now / filled for chunk q + NBUF - 1
         for (int q = q_begin; q < q_end; q++) {
-            // chunk q has landed (this wave's ten older DMAs; chunk q+1's ten may still fly); after the barrier every wave's
-            // have, and nobody reads buffer (q-1) % 3 any more -- which is where chunk q+2 goes
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            // chunk q has landed (three buffers: this wave's ten older DMAs; chunk q+1's ten may still fly); after the barrier
+            // every wave's have, and nobody reads the buffer of chunk q-1 any more -- which is where the next fetch goes
+            if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned char* rb = smem + cur;
-            W6_BEGIN(nxt2)
+            W6_BEGIN(nxt)
             LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)
-            WG_ROW(0, W6_P(0))
-            WG_ROW(1, W6_P(1))
-            WG_ROW(2, W6_P(2))
-            WG_ROW(3, W6_P(3))
-            WG_ROW(4, W6_P(4))
-            WG_ROW(5, W6_P(5))
-            WG_ROW(6, W6_D(0))
-            WG_ROW(7, W6_D(1))
-            WG_ROW(8, W6_D(2))
-            WG_ROW(9, W6_D(3))
-            cur = cur == 2 * BUF ? 0 : cur + BUF;
-            nxt2 = nxt2 == 2 * BUF ? 0 : nxt2 + BUF;
+            if constexpr (NBUF == 3) {
+                WG_ROW(0, W6_P(0))
+                WG_ROW(1, W6_P(1))
+                WG_ROW(2, W6_P(2))
+                WG_ROW(3, W6_P(3))
+                WG_ROW(4, W6_P(4))
+                WG_ROW(5, W6_P(5))
+                WG_ROW(6, W6_D(0))
+                WG_ROW(7, W6_D(1))
+                WG_ROW(8, W6_D(2))
+                WG_ROW(9, W6_D(3))
+            } else {
+                WG_ROW(0, W6_P(0) W6_P(1))
+                WG_ROW(1, W6_P(2) W6_P(3))
+                WG_ROW(2, W6_P(4) W6_P(5))
+                WG_ROW(3, W6_D(0) W6_D(1))
+                WG_ROW(4, W6_D(2) W6_D(3))
+                WG_ROW(5, )
+                WG_ROW(6, )
+                WG_ROW(7, )
+                WG_ROW(8, )
+                WG_ROW(9, )
+            }
+            cur = cur == (NBUF - 1) * BUF ? 0 : cur + BUF;
+            nxt = nxt == (NBUF - 1) * BUF ? 0 : nxt + BUF;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the two trailing (all-zero) chunks: nothing may land after exit
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (all-zero) fetches: nothing may land after exit
     }
 #undef W6_BEGIN
 #undef W6_P
@@ -647,10 +665,11 @@ __global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
     }
 }
 
+template <int NBUF>
 static int launch_wgrad6(const WgradArgs& a, hipStream_t st) {
-    auto kern = wgrad6_kernel;
-    BDN_SET_SMEM_ONCE(kern, Wg6::SMEM, "wgrad6");
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), Wg6::SMEM, st, a);
+    auto kern = wgrad6_kernel<NBUF>;
+    BDN_SET_SMEM_ONCE(kern, NBUF * Wg6::BUF, "wgrad6");
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), NBUF * Wg6::BUF, st, a);
     BDN_CHECK_LAUNCH("wgrad6");
     return BDN_OK;
 }
@@ -914,6 +933,7 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
     p.variant = pipe_ok ? (dma_ok ? BDN_WG_DMA : BDN_WG_PIPE) : BDN_WG_SIMPLE;
     if (want == BDN_WG_SIMPLE) p.variant = BDN_WG_SIMPLE;
     if (want == BDN_WG_PIPE && pipe_ok) p.variant = BDN_WG_PIPE;
+    if (want == BDN_WG_DMA2 && dma_ok) p.variant = BDN_WG_DMA2;
     // the simple kernel (first layer / 8x8 maps / f32) has no software pipeline: it hides latency with a second block per CU
     int blocks = (flags >> 16) & 0x1fff;
     if (blocks == 0) blocks = 256;                          // ~one block per CU: the kernel runs beside the dgrad chain on a second stream, so
@@ -981,7 +1001,8 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     int rc = BDN_OK;
     if (!(phases & 1)) {
     } else if (dtype == BDN_BF16) {
-        if (p.variant == BDN_WG_DMA) rc = launch_wgrad6(a, st);
+        if (p.variant == BDN_WG_DMA) rc = launch_wgrad6<3>(a, st);
+        else if (p.variant == BDN_WG_DMA2) rc = launch_wgrad6<2>(a, st);
         else if (p.variant == BDN_WG_PIPE) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
         else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import BDN_BF16, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_PIPE, call, ptr
+from ._lib import BDN_BF16, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_DMA2, WG_PIPE, call, ptr, wg_flags
 
 ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
@@ -178,6 +178,7 @@ class BiDateEngine:
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
         self.wgrad_dma = True           # A/B switch: relu(bn(z)) of the 'a' convs is materialised once on the weight-gradient stream and
                                         # the following conv's weight-gradient GEMM takes the LDS-DMA kernel (plain operands only)
+        self.wgrad_kernel = 0           # A/B: per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self._diag_skip_wgrad = False
         self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
@@ -399,8 +400,9 @@ class BiDateEngine:
             """The weight-gradient GEMM and its reduction; with profiling on, the GEMM alone sits between two events
             recorded on the stream it is launched on."""
             lib = _lib.load()
+            wk_ = self.wgrad_kernel
             if mode == IN_BNRELU and self.wgrad_dma and \
-                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, 0) == WG_DMA:
+                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_)) in (WG_DMA, WG_DMA2):
                 # the DMA kernel's operands never pass through registers: write a = relu(bn(z)) once (instead of deriving it in
                 # each of the Cout/64 column-tile blocks of the GEMM) and hand the GEMM a plain tensor
                 act = sc['act'][:in0.numel()]
@@ -410,9 +412,9 @@ class BiDateEngine:
                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
             name = None
             if self.prof is not None:
-                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, 0)
-                if v == WG_DMA:
-                    name = 'wgrad6_kernel'
+                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_))
+                if v in (WG_DMA, WG_DMA2):
+                    name = f'wgrad6_kernel<{3 if v == WG_DMA else 2}>'
                 elif v == WG_PIPE:
                     name = f'wgrad2_kernel<{"true" if mode == IN_BNRELU else "false"}>'
                 else:
@@ -426,13 +428,13 @@ class BiDateEngine:
                     if self._prof_seen - 1 != self.prof_pick:
                         name = None
             if name is None:
-                call('bdn_conv3x3_wgrad_ex', *args, 3, stp)
+                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(3, wk_), stp)
                 return
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            call('bdn_conv3x3_wgrad_ex', *args, 1, stp)
+            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(1, wk_), stp)
             e1.record()
-            call('bdn_conv3x3_wgrad_ex', *args, 2, stp)
+            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(2, wk_), stp)
             self.prof.append((name, 2.0 * n * hk * wk * L.cout * 9 * (c0 + c1), e0, e1))
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-enum { BDN_F32 = 0, BDN_BF16 = 1 };
+enum { BDN_F32 = 0, BDN_BF16 = 1, BDN_BF16X3 = 2 };   /* BDN_BF16X3: float32 tensors, GEMM operands split into bf16 hi + lo (3 MFMAs per product) */
 enum { BDN_OK = 0, BDN_E_ARG = -1, BDN_E_SHAPE = -2, BDN_E_HIP = -3 };
 enum { BDN_IN_PLAIN = 0, BDN_IN_BNRELU = 1 };
 
@@ -91,14 +91,15 @@ int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
 /* The same with a per-call `flags` word (there is no process-wide tuning state):
  *   bits 0-1   phases: bit 0 = split-K GEMM into `partial`, bit 1 = fixed-order reduction into dw_oihw (a profiler can
  *              bracket the GEMM alone by issuing the phases apart);
- *   bits 8-11  kernel override (0 = the library's choice): BDN_WG_SIMPLE, BDN_WG_PIPE, BDN_WG_DMA -- honoured where the
+ *   bits 8-11  kernel override (0 = the library's choice): BDN_WG_SIMPLE, BDN_WG_PIPE, BDN_WG_DMA, BDN_WG_DMA2 -- honoured where the
  *              shape class allows it, ignored otherwise (ask bdn_conv3x3_wgrad_variant what a call will run);
  *   bits 16-28 target number of blocks of the GEMM (0 = default 256, one per CU).
  * With non-default flags `partial` must hold bdn_wgrad_workspace_bytes_ex(same arguments).  Results are deterministic
  * for fixed flags; different plans differ only in the summation order of the partial tiles. */
 #define BDN_WG_SIMPLE 1      /* one-chunk-at-a-time kernel (any dtype, first layer, 8x8 maps) */
 #define BDN_WG_PIPE   2      /* software-pipelined bf16 kernel, operands staged through registers (BatchNorm+ReLU on load) */
-#define BDN_WG_DMA    3      /* bf16 kernel whose operands go HBM -> LDS by buffer_load ... lds (plain inputs only) */
+#define BDN_WG_DMA    3      /* bf16 kernel whose operands go HBM -> LDS by buffer_load ... lds (plain inputs only), 3 LDS buffers */
+#define BDN_WG_DMA2   4      /* the same with 2 LDS buffers (80 KB): leaves room for a convolution block on the same CU */
 #define BDN_WG_FLAGS(phases, kernel, blocks) ((phases) | ((kernel) << 8) | ((blocks) << 16))
 size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
                                     int in_mode, int flags);
