@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BIDATE_LIB') or os.path.join(_HERE, 'csrc', 'libbidate_hip.so')
 
-BDN_F32, BDN_BF16 = 0, 1
+BDN_F32, BDN_BF16, BDN_BF16X3 = 0, 1, 2
 IN_PLAIN, IN_BNRELU = 0, 1
 WG_SIMPLE, WG_PIPE, WG_DMA, WG_DMA2 = 1, 2, 3, 4
 
@@ -41,6 +41,7 @@ SIGNATURES = {
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_split_pack': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     'bdn_bnrelu': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

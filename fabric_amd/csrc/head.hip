@@ -63,6 +63,7 @@ extern "C" int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* 
         BDN_FAIL(BDN_E_SHAPE, "pack_weights: Cout must be a multiple of 32, Cin_pad of 16 (32 with a data-gradient image)");
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)Cout * 9 * Cin_pad;
+    if (dtype == BDN_BF16X3) return bdn_pack_weights_x3(w_oihw, wf, wd, Cout, Cin, Cin_pad, st);   // images of 3x the reduction length (x3.hip)
     if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16s>, dim3(grid_for(total)), dim3(256), 0, st, w_oihw, (bf16s*)wf, (bf16s*)wd, Cout, Cin, Cin_pad);
     else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, w_oihw, (float*)wf, (float*)wd, Cout, Cin, Cin_pad);
     else BDN_FAIL(BDN_E_ARG, "pack_weights: bad dtype");

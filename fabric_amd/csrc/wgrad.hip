@@ -949,15 +949,19 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
 extern "C" size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
                                                int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0 || imgs_per_group <= 0) return 0;
+    if (dtype == BDN_BF16X3)      // doubled operands ([hi | lo] x [hi | lo]) through the bf16 plan + the [2 Cout][2 Cin][9] tile the quadrants are summed from
+        return bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags)
+               + (size_t)4 * Cout * (C0 + C1) * 9 * sizeof(float);
     const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags);
     return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * (C0 + C1) * sizeof(float);
 }
 
 extern "C" size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cin, int imgs_per_group) {
-    // default flags, any dtype / source split / input mode: the largest plan (the simple kernel's, which both dtypes may take)
+    // default flags, any dtype / source split / input mode: the largest plan
     const size_t a = bdn_wgrad_workspace_bytes_ex(BDN_F32, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
     const size_t b = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
-    return a > b ? a : b;
+    const size_t c = bdn_wgrad_workspace_bytes_ex(BDN_BF16X3, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 template <typename T, int TH, int TW, int TI, bool KSPLIT>
@@ -980,6 +984,20 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
                                     int N, int H, int W, int phases, void* stream) {
     if (!dz || !in0 || !partial || !dw_oihw) BDN_FAIL(BDN_E_ARG, "wgrad: null pointer");
     if (!(phases & 3)) BDN_FAIL(BDN_E_ARG, "wgrad: phases must select the GEMM (1), the reduction (2) or both (3)");
+    if (dtype == BDN_BF16X3) {
+        // dz = split operand [N,H,W,2 Cout] (hi | lo), in0 = split operand [N,H,W,2 C0] from bdn_split_pack (which did any cat /
+        // BatchNorm+ReLU): the bf16 GEMM on the doubled operands yields T = [2 Cout][2 C0][9]; dw = T[hi,hi] + T[hi,lo] + T[lo,hi].
+        if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "wgrad(bf16x3): one split-packed, plain operand");
+        if (Cout <= 0 || Cout % 32 || C0 <= 0 || C0 % 8 || Cin_real <= 0 || Cin_real > C0)
+            BDN_FAIL(BDN_E_SHAPE, "wgrad(bf16x3): Cout=%d must be a multiple of 32, C0=%d of 8, Cin_real=%d <= C0", Cout, C0, Cin_real);
+        const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * C0, 0, imgs_per_group, BDN_IN_PLAIN, phases);
+        float* tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(partial) + gemm_bytes);
+        const int rc = bdn_conv3x3_wgrad_ex(BDN_BF16, dz, 2 * Cout, in0, 2 * C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group,
+                                            partial, tile, 2 * C0, N, H, W, phases, stream);
+        if (rc) return rc;
+        if (phases & 2) return bdn_wgrad_x3_combine(tile, dw_oihw, Cout, C0, Cin_real, reinterpret_cast<hipStream_t>(stream));
+        return BDN_OK;
+    }
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
         BDN_FAIL(BDN_E_SHAPE, "wgrad: bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
     if (Cout <= 0 || Cout % 64) BDN_FAIL(BDN_E_SHAPE, "wgrad: Cout=%d must be a multiple of 64", Cout);
@@ -1059,5 +1077,6 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
 // which kernel the GEMM phase runs for `flags` (bench.py names its roofline line after it): BDN_WG_SIMPLE / BDN_WG_PIPE / ...
 extern "C" int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || imgs_per_group <= 0) return 0;
+    if (dtype == BDN_BF16X3) return wgrad_plan(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags).variant;
     return wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags).variant;
 }

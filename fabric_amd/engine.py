@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import BDN_BF16, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_DMA2, WG_PIPE, call, ptr, wg_flags
+from ._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_DMA2, WG_PIPE, call, ptr, wg_flags
 
 ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
@@ -122,17 +122,28 @@ class Workspace:
             if L.enc:                                 # enc_skip_bwd leaves its BatchNorm-backward partials here too
                 n_stats = max(n_stats, 2 * lib.bdn_enc_skip_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(eng.dt, n, hk, wk, L.cout, ipg) // 4)
-            n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes(n, hk, wk, L.cout, L.cin, ipg) // 4)
+            if not eng.x3:                            # bf16x3 sizes its doubled-operand workspace per call (split_buf)
+                n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes_ex(eng.dt, n, hk, wk, L.cout, L.cin, 0, ipg, IN_PLAIN, 0) // 4)
         self.stats = f32(n_stats)
         self.bnws = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device=device)
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
-        self.n_wg1 = lib.bdn_wgrad_workspace_bytes(2 * B, H, W, L1.cout, L1.cin, B) // 4
+        self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, 0) // 4
         self.n_act = max(self.z[L.name].numel() for L in eng.layers if L.name.endswith('a'))
         self._bwd = None
+        self._split = {}
         self._outc_ws = None
         self.logits = None
         self.leased = False        # True while a live autograd graph still needs this workspace's z / bn tables for its backward
+
+    def split_buf(self, which, numel):
+        """bf16x3: scratch for a split GEMM operand ([.., 2C] bf16 = hi | lo).  'a' activations, 'd' gradients, 'w' the wgrad's own
+        activation operand; grown on demand, reused by every layer (single-stream schedule, so in-order reuse is safe)."""
+        t = self._split.get(which)
+        if t is None or t.numel() < numel:
+            t = torch.empty(numel, dtype=torch.bfloat16, device=self.x0.device)
+            self._split[which] = t
+        return t[:numel]
 
     def outc_ws(self, eng):
         """Scratch of bdn_outc_bwd (per-block partial classifier gradients)."""
@@ -154,15 +165,19 @@ class Workspace:
 class BiDateEngine:
     """Enqueues forward / backward of BiDateNet(n_channels, n_classes) on the HIP library.
 
-    precision: 'bf16' (bf16 activations and packed weights, fp32 accumulate -- throughput setting) or
-    'fp32' (f32 storage + f32 MFMA -- the 1e-3 parity setting).  Same kernels, one template parameter."""
+    precision: 'bf16' (bf16 activations and packed weights, fp32 accumulate -- throughput setting), 'fp32' (f32 storage +
+    f32 MFMA -- the exact parity setting, 1/16 of the bf16 matrix rate) or 'bf16x3' (f32 storage; every GEMM operand split into
+    bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate -- logits within 1e-3 of the reference at matrix-core speed).
+    Same kernels: one template parameter, resp. a three times longer reduction for the bf16 kernels."""
 
     def __init__(self, n_channels, n_classes, precision='bf16'):
-        if precision not in ('bf16', 'fp32'):
-            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        if precision not in ('bf16', 'fp32', 'bf16x3'):
+            raise ValueError(f"precision must be 'bf16', 'bf16x3' or 'fp32', got {precision!r}")
         self.n_channels, self.n_classes = n_channels, n_classes
         self.precision = precision
-        self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32
+        self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32                  # storage type: what the HBM-bound kernels see
+        self.mdt = BDN_BF16X3 if precision == 'bf16x3' else self.dt             # what the GEMM kernels (conv3x3, wgrad, weight packing) see
+        self.x3 = precision == 'bf16x3'
         self.tdtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.esize = 2 if precision == 'bf16' else 4
         self.cp = _round_up(n_channels, 16)
@@ -179,6 +194,13 @@ class BiDateEngine:
         self.wgrad_dma = True           # A/B switch: relu(bn(z)) of the 'a' convs is materialised once on the weight-gradient stream and
                                         # the following conv's weight-gradient GEMM takes the LDS-DMA kernel (plain operands only)
         self.wgrad_kernel = 0           # A/B: per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
+        self.wgrad_sched = 0            # how the weight-gradient GEMMs are placed beside the dz chain (both are MFMA-bound; two
+                                        # MFMA kernels sharing the chip LOSE throughput, an MFMA kernel beside an HBM-bound one gains):
+                                        #   0  released as soon as their dz exists (overlap whatever the chain runs next)
+                                        #   1  released after the layer's data-gradient conv, and the NEXT data-gradient conv waits for
+                                        #      them: they only ever run beside the HBM-bound kernels between two convs
+                                        #   2  like 1 but both GEMMs of a double_conv are released together after its second conv
+                                        #      (the long HBM phase: unpool / upsample backward + BatchNorm backward)
         self._diag_skip_wgrad = False
         self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
@@ -190,7 +212,7 @@ class BiDateEngine:
     # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
     def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg):
         """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to: asked from the library's own dispatcher."""
-        return _lib.load().bdn_conv3x3_variant(self.dt, n, h, w, c0, c1, cout, ipg).decode()
+        return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg).decode()
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
         name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
@@ -239,6 +261,21 @@ class BiDateEngine:
 
     def _pack_all(self, P):
         import struct
+        if self.x3:
+            # split filter images, three times the reduction length: [w_hi | w_hi | w_lo] (csrc/x3.hip); one launch per layer
+            ptrs = tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)
+            if self._pack_desc is None or self._pack_desc[0] != ptrs:
+                dev = P[f'{self.layers[0].conv}.weight'].device
+                self._packed = {L.conv: (torch.empty(L.cout, 9, 3 * L.cin, dtype=torch.bfloat16, device=dev),
+                                         torch.empty(L.cin, 9, 3 * L.cout, dtype=torch.bfloat16, device=dev) if L.name != 'e1a' else None)
+                                for L in self.layers}
+                self._pack_desc = (ptrs, None)
+            for L in self.layers:
+                wf, wd = self._packed[L.conv]
+                call('bdn_pack_weights', BDN_BF16X3, ptr(P[f'{L.conv}.weight']), ptr(wf), ptr(wd), L.cout, L.cin_real, L.cin, _lib.stream_ptr())
+            self._packed_versions = tuple(P[f'{L.conv}.weight']._version for L in self.layers)
+            self._packed_valid = True
+            return
         ptrs = tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)
         if self._pack_desc is None or self._pack_desc[0] != ptrs:
             dev = P[f'{self.layers[0].conv}.weight'].device
@@ -263,8 +300,13 @@ class BiDateEngine:
         hk, wk = ws.dims[L.level - 1]
         wf, _ = self._weights(L, P, False)
         z = ws.z[L.name]
+        if self.x3:
+            # the operand split does the cat and the BatchNorm+ReLU the f32 kernel would apply on load
+            sp = ws.split_buf('a', n * hk * wk * 2 * (c0 + c1))
+            call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
+            in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
         self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
-                         self.dt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
+                         self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
                          ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
                          n, hk, wk, L.cout, st)
         bn = ws.bn[L.name]
@@ -380,7 +422,7 @@ class BiDateEngine:
         e = lambda *s: torch.empty(*s, dtype=td, device=dev)
         ready = on_ready or (lambda keys: None)
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if wgrad_stream else None
+        side = self._side_stream(dev) if wgrad_stream and not self.x3 else None     # bf16x3 reuses one set of operand-split buffers: one stream
 
         def bn_bwd(L, dA, ldA, n, ipg, fused_rows=0):
             """BatchNorm+ReLU backward of layer L.  fused_rows > 0: the kernel that produced dA already left the
@@ -400,6 +442,16 @@ class BiDateEngine:
             """The weight-gradient GEMM and its reduction; with profiling on, the GEMM alone sits between two events
             recorded on the stream it is launched on."""
             lib = _lib.load()
+            if self.x3:
+                sd = ws.split_buf('d', n * hk * wk * 2 * L.cout)
+                sw = ws.split_buf('w', n * hk * wk * 2 * (c0 + c1))
+                call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sd), n, hk, wk, stp)
+                call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg, ptr(sw), n, hk, wk, stp)
+                nb = lib.bdn_wgrad_workspace_bytes_ex(BDN_BF16X3, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, 3)
+                part = ws.split_buf('p', nb // 2)
+                call('bdn_conv3x3_wgrad_ex', BDN_BF16X3, ptr(sd), L.cout, ptr(sw), c0 + c1, None, 0, IN_PLAIN, None, ipg,
+                     ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, 3, stp)
+                return
             wk_ = self.wgrad_kernel
             if mode == IN_BNRELU and self.wgrad_dma and \
                     lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_)) in (WG_DMA, WG_DMA2):
@@ -442,6 +494,9 @@ class BiDateEngine:
                 return
             hk, wk = ws.dims[L.level - 1]
             keys = [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias']
+            if side is not None and self.wgrad_sched:
+                pending.append((L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, keys))
+                return
             if side is None:
                 wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, st)
                 if zero_bias_grads:                  # feeds a BatchNorm: gradient is identically zero
@@ -457,19 +512,53 @@ class BiDateEngine:
                     grads[f'{L.conv}.bias'].zero_()
                 ready(keys)                          # a bucket all-reduce launched here is ordered behind this wgrad
 
+        pending, done = [], [None]
+
+        def release_wgrads():
+            """wgrad_sched 1/2: the chain has just enqueued a data-gradient conv and enters an HBM-bound phase: let the queued
+            weight-gradient GEMMs run beside it."""
+            if not pending:
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for (L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, keys) in pending:
+                    wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, side.cuda_stream)
+                    if zero_bias_grads:
+                        grads[f'{L.conv}.bias'].zero_()
+                    ready(keys)
+                d = torch.cuda.Event()
+                d.record(side)
+            done[0] = d
+            pending.clear()
+
         def dgrad(L, dz, n, ipg, prev=None):
             """Data gradient of layer L's conv.  prev = the layer whose relu(bn(z)) is this conv's input: its
             BatchNorm-backward partial sums are then produced by the epilogue (returns rows per statistic group)."""
+            out = dgrad_(L, dz, n, ipg, prev)
+            if self.wgrad_sched == 1 or (self.wgrad_sched == 2 and L.name.endswith('a')):
+                release_wgrads()
+            return out
+
+        def dgrad_(L, dz, n, ipg, prev=None):
+            if done[0] is not None:                  # the previous phase's weight-gradient GEMMs must be off the matrix cores
+                main.wait_event(done[0])
+                done[0] = None
             hk, wk = ws.dims[L.level - 1]
             _, wd = self._weights(L, P, True)
             out = e(n, hk, wk, L.cin)
+            if self.x3:
+                sp = ws.split_buf('d', n * hk * wk * 2 * L.cout)
+                call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sp), n, hk, wk, st)
+                dz = sp
             if prev is None or not self.fuse_bn_bwd_stats:
                 self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
-                                 self.dt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
+                                 self.mdt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
                                  ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
                 return out if prev is None else (out, 0)
             self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
-                             self.dt, ptr(dz), L.cout, ptr(wd), ptr(out), ptr(ws.z[prev.name]), ptr(ws.bn[prev.name]),
+                             self.mdt, ptr(dz), L.cout, ptr(wd), ptr(out), ptr(ws.z[prev.name]), ptr(ws.bn[prev.name]),
                              ipg, ptr(ws.stats), n, hk, wk, L.cin, st, fn='bdn_conv3x3_dgrad_bs')
             rows = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // (n // ipg)
             return out, rows
@@ -547,7 +636,7 @@ class BiDateEngine:
             if late:
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
             if k == 1 and rows and self.fuse_first_wgrad and \
-                    _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.dt, 2 * B, hk, wk, La.cout, La.cin, B):
+                    _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.mdt, 2 * B, hk, wk, La.cout, La.cin, B):
                 # the first conv has no data gradient: its dz has one reader, so the BatchNorm backward is applied inside
                 # that weight-gradient GEMM's staging and the largest tensor of the step is never written (on the main
                 # stream: nothing of the chain is left to run, the side stream is still busy with e1b's GEMM)
@@ -566,6 +655,7 @@ class BiDateEngine:
                         call('bdn_conv3x3_wgrad_bnbwd', *wargs)
                 if zero_bias_grads:
                     grads[f'{La.conv}.bias'].zero_()
+                release_wgrads()
                 if side is not None:
                     # this ready() may launch the LAST bucket's all-reduce, ordered behind the current (main) stream only;
                     # the bucket also holds e1b / e2a weight gradients whose GEMM + reduction are still queued on the side
@@ -583,6 +673,7 @@ class BiDateEngine:
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
             if late:
                 wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
+        release_wgrads()
         if side is not None:
             main.wait_stream(side)                   # every weight gradient is complete before the caller's next kernel
         return grads

@@ -78,6 +78,17 @@ int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad,
                          const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
                          int N, int H, int W, int Cout, void* stream);
 
+/* ---- bf16x3 operand split (dtype BDN_BF16X3 of bdn_conv3x3 / bdn_conv3x3_dgrad_bs / bdn_conv3x3_wgrad* / bdn_pack_weights) ----
+ * The 1e-3-parity setting at matrix-core speed: tensors stay float32; a GEMM operand x is fed as hi = bf16(x) and
+ * lo = bf16(x - hi) and a product keeps a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (float32 accumulate).  bdn_split_pack builds the
+ * operand every BDN_BF16X3 entry point expects: out [N,H,W,2(C0+C1)] bf16 = hi(a) | lo(a), a = cat(src0, src1) (f32 NHWC;
+ * src1 may be NULL) with relu(bn(.)) applied to src0 when in_mode == BDN_IN_BNRELU (models/unet_parts.py:14-15,78).
+ * With BDN_BF16X3: bdn_conv3x3 takes in0 = that tensor, C0 = the logical channel count, in1 = NULL, in_mode PLAIN, w from
+ * bdn_pack_weights(BDN_BF16X3) (wf: [Cout][9][3 Cin_pad] bf16, wd: [Cin_pad][9][3 Cout]), and writes float32 out / statistics;
+ * bdn_conv3x3_wgrad* take dz and in0 both split-packed and write the float32 OIHW gradient. */
+int bdn_split_pack(const float* src0, int C0, const float* src1, int C1, int in_mode, const float* in_bn,
+                   int imgs_per_group, void* out, int N, int H, int W, void* stream);
+
 /* ---- weight gradient of the same convolution (autograd of models/unet_parts.py:13,16) ----
  * dz: [N,H,W,Cout]; inputs as in bdn_conv3x3.  partial: workspace of bdn_wgrad_workspace_bytes().
  * dw_oihw: f32 [Cout,Cin_real,3,3] (overwritten; channels >= Cin_real of a padded input are dropped).

@@ -767,3 +767,91 @@ def test_wgrad_kernel_variants_agree(mode):
         assert torch.equal(out[WG_DMA], out[WG_PIPE])
     else:
         assert mode == 'bnrelu'                              # BatchNorm on load needs the register-staged kernel
+
+# ------------------------------------------------------------------ bf16x3: float32 tensors, bf16 hi/lo split GEMM operands
+def _split_ref(t_nchw):
+    """[N,C,H,W] f32 -> the [N,H,W,2C] bf16 operand bdn_split_pack must produce (hi | lo)."""
+    hi = t_nchw.to(torch.bfloat16)
+    lo = (t_nchw - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], 1).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('case', [(2, 9, 7, 16, 0, False), (4, 16, 16, 64, 64, False), (4, 12, 20, 128, 0, True)])
+def test_split_pack_is_the_exact_hi_lo_split(case):
+    """bdn_split_pack: hi = bf16(x), lo = bf16(x - hi) of cat(src0, src1) resp. relu(bn(src0)); hi + lo reproduces x to 2^-16."""
+    N, H, W, C0, C1, use_bn = case
+    ipg = N // 2
+    x0, x1 = _rand((N, C0, H, W), 301), (_rand((N, C1, H, W), 302) if C1 else None)
+    bn = bn_table(2, C0, 303)
+    a0 = bnrelu_ref('fp32', x0, bn, ipg) if use_bn else x0
+    full = torch.cat([a0, x1], 1) if C1 else a0
+    out = torch.empty(N, H, W, 2 * (C0 + C1), dtype=torch.bfloat16, device='cuda')
+    d0, d1 = to_nhwc('fp32', x0), (to_nhwc('fp32', x1) if C1 else None)
+    bn_d = dev(bn)
+    _lib.call('bdn_split_pack', d0.data_ptr(), C0, d1.data_ptr() if C1 else None, C1, IN_BNRELU if use_bn else IN_PLAIN,
+              bn_d.data_ptr(), ipg, out.data_ptr(), N, H, W, st())
+    torch.cuda.synchronize()
+    got = out.cpu()
+    if use_bn:      # the kernel's fma vs the reference's mul + add: compare the reconstructed value
+        rec = (got[..., :C0 + C1].float() + got[..., C0 + C1:].float()).permute(0, 3, 1, 2)
+        assert_close('hi+lo', rec, full, 2e-5)
+    else:
+        assert torch.equal(got, _split_ref(full))
+        rec = (got[..., :C0 + C1].float() + got[..., C0 + C1:].float()).permute(0, 3, 1, 2)
+        assert (rec - full).abs().max() <= 2.0 ** -16 * full.abs().max()
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 1), (2, 8, 8, 128, 64, 2), (1, 22, 45, 16, 64, 1), (3, 19, 33, 64, 128, 3),
+                                  (2, 12, 12, 192, 64, 2)])
+def test_conv3x3_bf16x3_forward_dgrad_wgrad(case):
+    """The bf16 kernels on split operands (three times the reduction length) against the float32 oracle: forward with
+    statistics, data gradient and weight gradient all within 1e-4 of the tensor's magnitude (a plain bf16 GEMM sits at 1e-2)."""
+    N, H, W, Cin, Cout, ipg = case
+    lib = _lib.load()
+    X3 = _lib.BDN_BF16X3
+    x = _rand((N, Cin, H, W), 311)
+    w = _rand((Cout, Cin, 3, 3), 312) * 0.1
+    b = _rand((Cout,), 313)
+    ref = F.conv2d(x, w, b, padding=1)
+    # forward
+    sp = torch.empty(N, H, W, 2 * Cin, dtype=torch.bfloat16, device='cuda')
+    xd = to_nhwc('fp32', x)
+    _lib.call('bdn_split_pack', xd.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg, sp.data_ptr(), N, H, W, st())
+    wf = torch.empty(Cout, 9, 3 * Cin, dtype=torch.bfloat16, device='cuda')
+    wd = torch.empty(Cin, 9, 3 * Cout, dtype=torch.bfloat16, device='cuda') if Cin % 64 == 0 else None
+    wdev = dev(w)
+    _lib.call('bdn_pack_weights', X3, wdev.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else None, Cout, Cin, Cin, st())
+    out = torch.full((N, H, W, Cout), float('nan'), device='cuda')
+    nt = lib.bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
+    stats = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    bd = dev(b)
+    _lib.call('bdn_conv3x3', X3, sp.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg, wf.data_ptr(), bd.data_ptr(), out.data_ptr(),
+              stats.data_ptr(), N, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert_close('x3 fwd', from_nhwc(out), ref, 1e-4)
+    G = N // ipg
+    ssum = stats[:, 0].cpu().double().reshape(G, -1, Cout).sum(1)
+    want = ref.double().reshape(G, ipg, Cout, H * W).sum((1, 3))
+    assert (ssum - want).abs().max() <= 1e-4 * want.abs().max() + 1e-3
+    with pytest.raises(RuntimeError):          # the split operand carries cat and BatchNorm already
+        _lib.call('bdn_conv3x3', X3, sp.data_ptr(), Cin, None, 0, IN_BNRELU, bd.data_ptr(), ipg, wf.data_ptr(), bd.data_ptr(),
+                  out.data_ptr(), None, N, H, W, Cout, st())
+    # gradients
+    dz = _rand((N, Cout, H, W), 314)
+    dzd = to_nhwc('fp32', dz)
+    spd = torch.empty(N, H, W, 2 * Cout, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', dzd.data_ptr(), Cout, None, 0, IN_PLAIN, None, ipg, spd.data_ptr(), N, H, W, st())
+    if wd is not None:
+        dA = torch.full((N, H, W, Cin), float('nan'), device='cuda')
+        _lib.call('bdn_conv3x3', X3, spd.data_ptr(), Cout, None, 0, IN_PLAIN, None, ipg, wd.data_ptr(), None, dA.data_ptr(), None,
+                  N, H, W, Cin, st())
+        torch.cuda.synchronize()
+        assert_close('x3 dgrad', from_nhwc(dA), torch.nn.grad.conv2d_input(x.shape, w, dz, padding=1), 1e-4)
+    nb = lib.bdn_wgrad_workspace_bytes_ex(X3, N, H, W, Cout, Cin, 0, ipg, IN_PLAIN, 3)
+    assert nb <= lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, Cin, ipg)
+    part = torch.empty(nb // 4, device='cuda')
+    dw = torch.full((Cout, Cin, 3, 3), float('nan'), device='cuda')
+    _lib.call('bdn_conv3x3_wgrad', X3, spd.data_ptr(), Cout, sp.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg,
+              part.data_ptr(), dw.data_ptr(), Cin, N, H, W, st())
+    torch.cuda.synchronize()
+    assert_close('x3 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz, padding=1), 1e-4)

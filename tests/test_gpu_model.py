@@ -75,7 +75,7 @@ def _grad_errors(model, g):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16'])
 def test_train_step_matches_reference(golden_dir, name, prec):
     g, c, x1, x2, lbl = _load(golden_dir, name)
     model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda()
@@ -92,11 +92,13 @@ def test_train_step_matches_reference(golden_dir, name, prec):
     gerr, gkey, gcos = _grad_errors(model, g)
     print(f'\n[{name} {prec}] max|dlogit|={d.max():.3e} mean={d.mean():.3e} argmax agree={agree:.4f} '
           f'loss={loss.item():.6f} (ref {float(g["loss"]):.6f}) worst grad err={gerr:.3e} @ {gkey} cos={gcos:.4f}')
-    if prec == 'fp32':
+    if prec in ('fp32', 'bf16x3'):
+        # the 1e-3 parity bar of north_star holds in BOTH float32-class settings: exact f32 MFMA, and bf16 hi/lo split operands
+        # (three bf16 MFMAs per product; 2^-16 relative per product, measured <= 2e-4 on the logits)
         assert d.max() <= 1e-3
         margin = (ref[:, 0] - ref[:, 1]).abs()
         assert ((got.argmax(1) == ref.argmax(1)) | (margin < 2e-3)).all()
-        assert abs(loss.item() - float(g['loss'])) < 1e-5
+        assert abs(loss.item() - float(g['loss'])) < (1e-5 if prec == 'fp32' else 5e-5)
         assert gerr < 2e-2 and gcos > 0.9999, (gkey, gerr, gcos)
     else:
         assert d.max() <= 0.25 and d.mean() <= 0.03
@@ -105,7 +107,7 @@ def test_train_step_matches_reference(golden_dir, name, prec):
         assert gerr < 0.8 and gcos >= 0.97, (gkey, gerr, gcos)
     # BatchNorm running buffers after ONE forward: updated twice (date 1 then date 2)
     sd = model.state_dict()
-    btol = 1e-4 if prec == 'fp32' else 2e-2
+    btol = 2e-2 if prec == 'bf16' else 1e-4
     for k in sd:
         if 'running_' in k:
             ref_b = torch.from_numpy(g['buf/' + k])
@@ -116,7 +118,7 @@ def test_train_step_matches_reference(golden_dir, name, prec):
     opt.step()
     logits2 = model(x1, x2).detach().cpu()
     d2 = (logits2 - torch.from_numpy(g['logits_after_step'])).abs()
-    assert d2.max() <= (1e-3 if prec == 'fp32' else 0.25)
+    assert d2.max() <= (0.25 if prec == 'bf16' else 1e-3)
 
 
 @pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
@@ -207,7 +209,7 @@ def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, pre
 
 
 @pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90'])
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16'])
 def test_eval_mode_matches_reference(golden_dir, name, prec):
     g, c, x1, x2, _ = _load(golden_dir, name)
     model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda().eval()
@@ -217,7 +219,7 @@ def test_eval_mode_matches_reference(golden_dir, name, prec):
     scale = ref.abs().max().item()             # the filler's running statistics give O(100) eval logits
     d = (got - ref).abs().max().item()
     print(f'\n[{name} {prec} eval] max|dlogit|={d:.3e} of scale {scale:.1f}')
-    assert d <= (2e-5 if prec == 'fp32' else 3e-2) * scale
+    assert d <= {'fp32': 2e-5, 'bf16x3': 1e-4, 'bf16': 3e-2}[prec] * scale
     sd = model.state_dict()
     assert all(int(sd[k]) == 0 for k in sd if 'num_batches_tracked' in k)    # eval must not touch the buffers
 
