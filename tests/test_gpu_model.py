@@ -106,7 +106,7 @@ def test_train_step_matches_reference(golden_dir, name, prec):
         assert d.max() <= 0.25 and d.mean() <= 0.03
         assert agree >= 0.96
         assert abs(loss.item() - float(g['loss'])) < 5e-3
-        assert gerr < 0.8 and gcos >= 0.97, (gkey, gerr, gcos)
+        assert gerr < 0.8 and gcos >= 0.99, (gkey, gerr, gcos)      # measured: per-parameter 0.35-0.62, whole-vector cosine >= 0.995
     # BatchNorm running buffers after ONE forward: updated twice (date 1 then date 2)
     sd = model.state_dict()
     btol = 2e-2 if prec == 'bf16' else 1e-4
