@@ -7,15 +7,20 @@ backward + gradient all-reduce + SGD) on synthetic 13-band 128x128 patch pairs, 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- the dominant kernel (largest summed time of the conv3x3_kernel instantiations, i.e.
-                  3x3 forward + data-gradient launches): algorithmic FLOP per launch / average launch
-                  time measured with HIP events on the launch stream inside the timed region,
-                  against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md);
-  cpu_baseline -- the oracle's stock-torch assembly of the reference graph timed on this box's host
-                  cores (rank 0, N=1 only; bounded sample).  A reported baseline, not the target.
+Prints ONE JSON line on rank 0 (contract in the task description).  `value` is measured with the inputs resident in HBM.
+Extra objects on the same line:
+  roofline       the dominant MFMA kernel of the step: algorithmic FLOP per launch / launch time measured with HIP events on
+                 the launch stream inside the timed region (one launch bracketed per step, every launch shape weighted
+                 equally), against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); HBM bytes per launch and
+                 per step from the committed PMC passes (profiles/);
+  cpu_baseline   the oracle's stock-torch assembly of the reference graph timed on ALL host cores (rank 0, N=1 only);
+  host_fed       the same step fed from pinned HOST memory through fabric_amd.input_pipeline.DeviceFeeder (PCIe inclusive);
+  parity_setting pairs/s of the two float32-class settings (bf16x3: logits within 1e-3; fp32: exact f32 MFMA);
+  scene          BASELINE configs[4]: full-scene sliding-window inference of a 13-band 10000 x 10000 scene pair.
 """
 import argparse
+import csv
+import glob
 import json
 import os
 import sys
@@ -28,17 +33,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR_FWD_BWD = 69.43e9
+FLOP_PER_PAIR_FWD = 23.144e9
 MFMA_BF16_PEAK = 2.5e15                  # dense, MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12
+HBM_PEAK = 8.0e12
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def cpu_baseline(seconds_budget=25.0):
-    """Reference CPU path (oracle port) on the host cores: fwd + Tversky + bwd + SGD, fp32, B=16."""
+    """Reference CPU path (oracle port) on ALL host cores: fwd + Tversky + bwd + SGD, fp32, B=16."""
     from oracle import bidate_oracle as O
     from oracle import filler
     ncores = os.cpu_count() or 1
-    threads = min(ncores, 64)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(ncores)
     B = 16
     x1, x2, lbl = filler.make_inputs(B, 13, 128, seed=0)
     x1, x2, lbl = torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl).long()
@@ -60,42 +76,177 @@ def cpu_baseline(seconds_budget=25.0):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {'value': B / med, 'unit': 'patch-pairs/s', 'cores': threads, 'kind': 'port',
+    return {'value': B / med, 'unit': 'patch-pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'{len(times)} steps of B={B} 13x128x128 fwd+Tversky+bwd+SGD, fp32 stock torch.nn '
-                      f'assembly of the reference graph (oracle.build_torch_baseline), median; '
-                      f'{threads} threads of {ncores} host CPUs'}
+                      f'assembly of the reference graph (oracle.build_torch_baseline, forward pinned to the golden logits by '
+                      f'tests/test_oracle_cpu.py), median; {torch.get_num_threads()} threads = all {ncores} host CPUs ({_cpu_model()})'}
+
+
+# ---------------------------------------------------------------------------------------------- committed profile artefacts
+def _latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    return files[-1] if files else None
+
+
+def _kkey(kernel):
+    return kernel.replace('bf16', 'unsigned short').replace(',', ', ')
+
+
+def pmc_tables(precision):
+    """(per-kernel dict, path) of the newest committed PMC summary (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE collected in
+    separate rocprofv3 --pmc passes of this same bench, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    path = _latest('r*_pmc_traffic.json')
+    if precision != 'bf16' or not path:
+        return None, None
+    return json.load(open(path)), path
 
 
 def pmc_traffic(kernel, precision):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary is committed for this kernel."""
-    path = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-    if precision != 'bf16' or not os.path.exists(path):
+    tab, path = pmc_tables(precision)
+    if not tab:
         return None
-    key = kernel.replace('bf16', 'unsigned short').replace(',', ', ')
-    rec = json.load(open(path)).get(key)   # e.g. 'conv3x3_kernel<unsigned short, 128, ...>' or 'wgrad2_kernel<true>'
+    rec = tab.get(_kkey(kernel))
+    if not rec:       # template spellings differ between rocprofv3 versions: match on the name up to the argument list
+        cand = [v for k, v in tab.items() if k.startswith(_kkey(kernel).split('<')[0]) and _kkey(kernel).rstrip('>') in k]
+        rec = cand[0] if cand else None
     if not rec:
         return None
     return {'unit': 'bytes/launch', 'hbm_read': rec['fetch_bytes_per_launch_corrected'],
-            'hbm_write': rec['write_bytes_per_launch'], 'source': 'profiles/r1_pmc_traffic.json',
+            'hbm_write': rec['write_bytes_per_launch'], 'source': os.path.relpath(path, ROOT),
             'correction': 'FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported; separate --pmc passes'}
 
 
-def rocprof_avg_us(kernel, precision):
-    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
-    (profiles/r1_d_kernel_stats.csv), for comparison with the live event figure.  The event interval additionally
-    contains the dispatch wait behind the side-stream weight-gradient blocks that hold the CUs when the kernel is
-    enqueued (rocprofv3 counts a kernel from its first wave), so it is the larger of the two."""
-    path = os.path.join(ROOT, 'profiles', 'r1_d_kernel_stats.csv')
-    if precision != 'bf16' or not os.path.exists(path):
+def pmc_step_bytes(precision):
+    """HBM bytes of one whole training step: sum over every kernel of the committed PMC summary."""
+    tab, path = pmc_tables(precision)
+    if not tab or '_meta' not in tab:
         return None
-    import csv
-    key = 'void ' + kernel.replace('bf16', 'unsigned short').replace(',', ', ') + '('
+    steps = tab['_meta']['steps']
+    tot = sum((v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch']) * v['launches']
+              for k, v in tab.items() if k != '_meta')
+    return tot / steps, os.path.relpath(path, ROOT)
+
+
+def rocprof_avg_us(kernel, precision):
+    """Average duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of this same command."""
+    path = _latest('r*_kernel_stats.csv')
+    if precision != 'bf16' or not path:
+        return None, None
+    key = 'void ' + _kkey(kernel)
     for r in csv.DictReader(open(path)):
         if r['Name'].startswith(key):
-            return float(r['AverageNs']) / 1e3
-    return None
+            return float(r['AverageNs']) / 1e3, os.path.relpath(path, ROOT)
+    return None, os.path.relpath(path, ROOT)
+
+
+# ---------------------------------------------------------------------------------------------- extra legs (rank 0, N = 1)
+def _time_steps(ts, x1, x2, lbl, warm, n):
+    for _ in range(warm):
+        ts.step(x1, x2, lbl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ts.step(x1, x2, lbl)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def host_fed_leg(ts, dev, B, C, S, steps, warmup, resident_ms):
+    """The step fed from pinned host memory: float32 NCHW pairs + uint8 labels cross PCIe every step on a copy stream, under the
+    previous step (fabric_amd/input_pipeline.py; reference train.py:83-85 copies on the compute stream)."""
+    from fabric_amd.input_pipeline import DeviceFeeder
+    g = torch.Generator(device='cpu').manual_seed(7)
+    pool = []
+    for _ in range(3):
+        x1 = torch.randn(B, C, S, S, generator=g)
+        pool.append((x1.pin_memory(), (x1 + 0.3 * torch.randn(B, C, S, S, generator=g)).pin_memory(),
+                     (torch.rand(B, S, S, generator=g) < 0.1).to(torch.uint8).pin_memory()))
+    feeder = DeviceFeeder(dev, depth=2)
+
+    def batches(n):
+        for i in range(n):
+            yield pool[i % len(pool)]
+    for b in feeder(batches(warmup)):
+        ts.step(*b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in feeder(batches(steps)):
+        ts.step(*b)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    nbytes = sum(t.numel() * t.element_size() for t in pool[0])
+    return {'value': B / ms * 1e3, 'unit': 'patch-pairs/s', 'ms_per_step': ms, 'vs_resident': resident_ms / ms,
+            'host_bytes_per_step': nbytes, 'pcie_GBps_sustained': nbytes / ms / 1e6,
+            'how': 'pinned host batches -> DeviceFeeder (copy stream, 2 device slots, event hand-off) -> TrainStep; '
+                   'PCIe-inclusive, never the headline value'}
+
+
+def parity_leg(dev, B, C, S):
+    """The float32-class settings at the benchmark shape: pairs/s, and how far bf16x3 / bf16 logits sit from the exact-f32
+    setting on the same weights and inputs (the f32 setting itself is pinned to the reference within 3e-5 by tests/)."""
+    from fabric_amd import BiDateNet
+    from fabric_amd.train_step import TrainStep
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x1 = torch.randn(B, C, S, S, generator=g)
+    x2 = (x1 + 0.3 * torch.randn(B, C, S, S, generator=g)).to(dev)
+    x1 = x1.to(dev)
+    lbl = (torch.rand(B, S, S, generator=g) < 0.1).to(torch.uint8).to(dev)
+    torch.manual_seed(4321)
+    sd = {k: v.clone() for k, v in BiDateNet(C, 2).state_dict().items()}
+    out, logits = {}, {}
+    for prec, warm, n in (('fp32', 1, 3), ('bf16x3', 2, 6), ('bf16', 2, 6)):
+        m = BiDateNet(C, 2, precision=prec)
+        m.load_state_dict(sd)
+        m = m.to(dev).train()
+        with torch.no_grad():
+            logits[prec] = m(x1[:8], x2[:8]).float().clone()
+        if prec != 'bf16':
+            ts = TrainStep(m, lr=1e-3)
+            ms = _time_steps(ts, x1, x2, lbl, warm, n) * 1e3
+            out[prec] = {'pairs_per_s': B / ms * 1e3, 'ms_per_step': ms}
+            del ts
+        del m
+        torch.cuda.empty_cache()
+    for prec in ('bf16x3', 'bf16'):
+        out.setdefault(prec, {})['max_abs_dlogit_vs_fp32_setting'] = float((logits[prec] - logits['fp32']).abs().max())
+    out['tolerance'] = 'north_star: logits within 1e-3 of the reference; tests/test_gpu_model.py holds fp32 and bf16x3 to it on the golden vectors'
+    out['bf16x3']['how'] = 'float32 tensors; GEMM operands split into bf16 hi + lo, a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on the bf16 MFMA kernels (csrc/x3.hip)'
+    out['fp32']['how'] = 'float32 tensors; v_mfma_f32_32x32x2_f32 (1/16 of the bf16 matrix rate)'
+    return out
+
+
+def scene_leg(dev, size=10000, batch=64, reps=2):
+    """BASELINE.json configs[4]: forward-only sliding-window inference of a 13-band size x size scene pair (6241 tiles at 10000:
+    reference train.py:182-205 / utils/inference.py:134-236), scene planes resident in HBM as float32."""
+    from fabric_amd import BiDateNet
+    from fabric_amd.utils import inference as inf
+    torch.manual_seed(0)
+    model = BiDateNet(13, 2, precision='bf16').to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(3)
+    d1 = torch.randn(13, size, size, device=dev, generator=g)
+    d2 = d1 + 0.3 * torch.randn(13, size, size, device=dev, generator=g)
+    n = len(inf.tile_origins(size, size, 128)[0])
+    inf.predict_scene(model, d1, d2, 128, batch)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t = time.perf_counter()
+        mask = inf.predict_scene(model, d1, d2, 128, batch)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t)
+    flops = n * FLOP_PER_PAIR_FWD
+    act_bytes = n * 45.9e6 + 2 * 13 * size * size * 4           # BASELINE.md: ideal conv activation traffic + one read of the scene
+    out = {'workload': f'13-band {size}x{size} scene pair, 128-px tiles, batch {batch}, forward only, bf16 (BASELINE configs[4])',
+           'tiles': n, 'seconds': best, 'tiles_per_s': n / best, 'mpix_per_s': size * size / best / 1e6,
+           'changed_fraction': float(mask.float().mean()),
+           'roofline': {'bound': 'mfma', 'achieved': flops / best / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                        'frac': flops / best / MFMA_BF16_PEAK,
+                        'note': 'BASELINE calls the regime HBM-bound; with the scene resident and tiles gathered on the device the forward '
+                                'convolutions bound it (144 TFLOP vs 0.3 TB of ideal activation traffic)'},
+           'hbm_algorithmic': {'bytes': act_bytes, 'GBps': act_bytes / best / 1e9, 'frac_of_peak': act_bytes / best / HBM_PEAK}}
+    del d1, d2, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -106,9 +257,11 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='patch pairs per GPU')
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--channels', type=int, default=13)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP events')
+    ap.add_argument('--no-extras', action='store_true', help='skip the host_fed / parity_setting / scene legs')
+    ap.add_argument('--scene-size', type=int, default=10000)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -143,9 +296,8 @@ def main():
     eng = model.engine()
     for _ in range(args.warmup):
         ts.step(x1, x2, lbl)
-    # Which MFMA kernel (conv3x3 instantiation or weight-gradient GEMM) dominates?  One fully instrumented, UNTIMED step decides (every event pair is a
-    # ~150 us pipeline bubble on this stack, so the timed region only brackets the launches of that one kernel,
-    # and only during its first EVENT_STEPS steps).
+    # Which MFMA kernel (conv3x3 instantiation or weight-gradient GEMM) dominates?  One fully instrumented, UNTIMED step decides
+    # (every event pair is a pipeline bubble, so the timed region brackets ONE launch of that kernel per step).
     conv_all = None
     if not args.no_roofline:
         torch.cuda.synchronize()
@@ -161,15 +313,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # One event pair per step: step i brackets the (i mod n)-th launch of the dominant kernel, so every launch shape is
-    # sampled equally often over the timed region while the pipeline sees a single ~5 us bubble per step (bracketing
-    # all 18 launches of a step let the side-stream weight-gradient GEMMs crowd in and inflated the durations 30 %).
     n_dom = conv_all[eng.prof_filter][0] if not args.no_roofline else 0
     if not args.no_roofline:
         eng.prof = []
+    picks = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.prof_pick = i % n_dom if n_dom else None
+        eng.prof_pick = i % n_dom if n_dom else None          # step i brackets the (i mod n)-th launch of the dominant kernel
+        picks.append(eng.prof_pick)
         loss = ts.step(x1, x2, lbl)
     if world > 1:
         dist.barrier()
@@ -181,46 +332,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    ms_step = elapsed / args.steps * 1e3
 
     roofline = None
     if prof:
-        agg = {}
-        for name, flops, e0, e1 in prof:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
-        name, (cnt, flops, secs) = max(agg.items(), key=lambda kv: kv[1][2])
-        peak = MFMA_BF16_PEAK if args.precision == 'bf16' else MFMA_F32_PEAK
-        achieved = flops / secs
+        name = eng.prof_filter
+        # one sample per step, launch shapes round robin; every SHAPE gets the same weight whatever K mod n is:
+        # achieved = sum over shapes of its FLOP / sum over shapes of its mean duration
+        per = {}
+        for (nm, flops, e0, e1), pk in zip(prof, picks):
+            a = per.setdefault(pk, [flops, []])
+            a[1].append(e0.elapsed_time(e1) * 1e-3)
+        flop_sum = sum(v[0] for v in per.values())
+        time_sum = sum(sum(v[1]) / len(v[1]) for v in per.values())
+        peak = MFMA_F32_PEAK if args.precision == 'fp32' else MFMA_BF16_PEAK
+        achieved = flop_sum / time_sum
         conv_total = sum(v[2] for v in conv_all.values())
+        tr = pmc_traffic(name, args.precision)
+        ravg, rsrc = rocprof_avg_us(name, args.precision)
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved / 1e12, 'peak': peak / 1e12,
                     'unit': 'TFLOP/s', 'frac': achieved / peak,
-                    'traffic': (lambda t: None if t is None else t['hbm_read'] + t['hbm_write'])(pmc_traffic(name, args.precision)),
-                    'traffic_detail': pmc_traffic(name, args.precision),
-                    'launches_per_step': n_dom, 'sampled_launches': cnt, 'sampling': 'one launch per timed step, round robin',
-                    'avg_launch_us': secs / cnt * 1e6, 'rocprof_avg_launch_us': rocprof_avg_us(name, args.precision),
-                    'flop_per_launch': flops / cnt,
+                    'traffic': None if tr is None else tr['hbm_read'] + tr['hbm_write'], 'traffic_detail': tr,
+                    'launches_per_step': n_dom, 'sampled_launches': len(prof), 'shapes_sampled': len(per),
+                    'sampling': 'one launch per timed step, round robin over the launches of a step; shapes weighted equally',
+                    'avg_launch_us': time_sum / len(per) * 1e6, 'rocprof_avg_launch_us': ravg, 'rocprof_source': rsrc,
+                    'flop_per_launch': flop_sum / len(per),
                     'all_mfma_kernels': {'source': 'one fully instrumented untimed step (conv3x3 fwd/dgrad + weight-gradient GEMMs)',
-                                             'per_kernel_ms': {k: round(v[2] * 1e3, 3) for k, v in sorted(conv_all.items(), key=lambda kv: -kv[1][2])},
-                                             'seconds_per_step': conv_total,
-                                             'achieved': sum(v[1] for v in conv_all.values()) / conv_total / 1e12}}
+                                         'per_kernel_ms': {k: round(v[2] * 1e3, 3) for k, v in sorted(conv_all.items(), key=lambda kv: -kv[1][2])},
+                                         'seconds_per_step': conv_total,
+                                         'achieved': sum(v[1] for v in conv_all.values()) / conv_total / 1e12}}
     if rank == 0:
         pairs = args.steps * B * world
         value = pairs / elapsed
+        peak = MFMA_F32_PEAK if args.precision == 'fp32' else MFMA_BF16_PEAK
         out = {
             'metric': 'patch-pairs/sec (fwd+bwd) 13-band 128x128', 'value': value, 'unit': 'patch-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'BiDateNet({C},2) {C}-band {S}x{S} patch pairs, batch {B}/GPU, '
                                    f'fwd + Tversky + bwd + grad all-reduce + SGD (BASELINE configs[{1 if world == 1 else 2}])',
                        'global_batch': B * world, 'patch': S, 'bands': C,
-                       'parallelism': f'dp{world}', 'precision': args.precision},
-            'step_mfma_frac': value * FLOP_PER_PAIR_FWD_BWD / (world * (MFMA_BF16_PEAK if args.precision == 'bf16' else MFMA_F32_PEAK)),
+                       'parallelism': f'dp{world}', 'precision': args.precision, 'inputs': 'resident in HBM'},
+            'step_mfma_frac': value * FLOP_PER_PAIR_FWD_BWD / (world * peak),
             'final_loss': loss_val,
             'roofline': roofline,
         }
+        hb = pmc_step_bytes(args.precision)
+        if hb is not None:
+            out['hbm_bytes_per_step'] = hb[0]
+            out['hbm_frac'] = hb[0] / (ms_step * 1e-3) / HBM_PEAK
+            out['hbm_source'] = hb[1] + ' (PMC FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of a step; bytes/step divided by this run\'s step time and 8 TB/s)'
+        if world == 1 and not args.no_extras and args.precision == 'bf16':
+            out['host_fed'] = host_fed_leg(ts, dev, B, C, S, args.steps, args.warmup, ms_step)
+            del ts, model, eng, x1, x2, lbl
+            torch.cuda.empty_cache()
+            out['parity_setting'] = parity_leg(dev, B, C, S)
+            out['scene'] = scene_leg(dev, size=args.scene_size)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -38,19 +38,22 @@ def make_loaders(full_load, val_cities, patch_size, stride, batch_size, augmenta
     val_ds = OneraPreloader('', val_meta, full_load, patch_size, False)
     if world_size > 1:
         train_ds = torch.utils.data.Subset(train_ds, shard_indices(len(train_ds), rank, world_size))
-    kw = dict(batch_size=batch_size, num_workers=num_workers)
+    kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=True)   # pinned batches: the copy stream DMAs them without staging
     return (torch.utils.data.DataLoader(train_ds, shuffle=True, drop_last=True, **kw),
             torch.utils.data.DataLoader(val_ds, shuffle=False, **kw))
 
 
-def train_epoch(step, loader, dev, patch_size):
-    """train.py:73-118 without the per-step host round trip: losses / counts are read back once per epoch."""
+def train_epoch(step, loader, dev, patch_size, feeder=None):
+    """train.py:73-118 without the per-step host round trip: losses / counts are read back once per epoch, and the
+    host -> device copies of batch k+1 (train.py:83-85) run on a copy stream under the step of batch k."""
+    from .input_pipeline import DeviceFeeder
     step.model.train()
     recs = []
+    feeder = feeder or DeviceFeeder(dev)
     with torch.cuda.stream(step.stream()):                # the loop lives on the step's own stream: no joins per step
-        for b1, b2, labels in loader:
-            loss = step.step(b1.to(dev, non_blocking=True), b2.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
-            recs.append((loss.clone(), step.last_counts.clone(), labels.shape[0]))
+        for b1, b2, labels in feeder(loader):
+            loss = step.step(b1, b2, labels)
+            recs.append((loss, step.last_counts.clone(), labels.shape[0]))
     torch.cuda.current_stream(dev).wait_stream(step.stream())
     metrics = initialize_metrics()
     for loss, counts, n in recs:

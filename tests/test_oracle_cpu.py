@@ -129,3 +129,23 @@ def test_losses_more_match_golden(golden_dir):
                 v.backward()
                 assert abs(float(v) - float(g[f'{tag}/{name}_{rank}'])) < 1e-6
                 assert np.abs(lg.grad.numpy() - g[f'{tag}/d{name}_{rank}']).max() < 1e-7
+
+
+@pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g2_c13_b2_s128'])
+def test_timed_cpu_baseline_graph_reproduces_the_reference_logits(golden_dir, name):
+    """bench.py's cpu_baseline leg times oracle.build_torch_baseline (stock torch.nn modules assembled like
+    models/bidate_model.py:22-40): its forward + Tversky + backward must be the reference's, not merely have its keys."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    c, b, s, sw, dd = [int(v) for v in g['meta']]
+    x1, x2, lbl = filler.make_inputs(b, c, s, seed=0, different_dates=bool(dd), size_w=sw)
+    net = filler.fill_module(O.build_torch_baseline(c, 2)).train()
+    logits = net(torch.from_numpy(x1), torch.from_numpy(x2))
+    assert np.abs(logits.detach().numpy() - g['logits']).max() < 5e-5
+    loss = O.tversky_loss(logits, torch.from_numpy(lbl).long(), 0.1, 0.9)
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    loss.backward()
+    for k, p in net.named_parameters():
+        if float(g['gnorm/' + k]) < 1e-6:
+            continue
+        got = p.grad.reshape(-1)[torch.from_numpy(g['gidx/' + k])].numpy()
+        assert np.linalg.norm(got - g['gsamp/' + k]) <= 2e-2 * np.linalg.norm(g['gsamp/' + k]) + 1e-9, k
