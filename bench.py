@@ -49,12 +49,18 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Reference CPU path (oracle port) on ALL host cores: fwd + Tversky + bwd + SGD, fp32, B=16."""
+def cpu_baseline(seconds_budget=28.0):
+    """Reference CPU path (oracle port) on the host cores: fwd + Tversky + bwd + SGD, fp32, B=16.
+    "All cores" is tried, but so are smaller thread counts: stock torch/oneDNN gets SLOWER past one thread per physical core
+    on the big two-socket hosts (256 logical CPUs: 0.17 pairs/s against 4.7 with 64 threads), and a baseline should be the
+    reference's best configuration.  The best is reported as `value` with its thread count in `cores`; every count tried is
+    listed in `sample`."""
     from oracle import bidate_oracle as O
     from oracle import filler
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
     B = 16
     x1, x2, lbl = filler.make_inputs(B, 13, 128, seed=0)
     x1, x2, lbl = torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl).long()
@@ -67,19 +73,36 @@ def cpu_baseline(seconds_budget=25.0):
         loss.backward()
         opt.step()
 
-    step()                                   # warm-up (oneDNN primitive creation)
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_start) < seconds_budget:
+    tried, t_start = [], time.perf_counter()
+    cands = []
+    for th in (min(ncores, 64), max(1, ncores // 2), ncores, min(ncores, 32)):     # 64 first: one thread per core of one socket
+        if th not in cands:
+            cands.append(th)
+    for th in cands:
+        left = seconds_budget - (time.perf_counter() - t_start)
+        done_ = [t for t in tried if t[1] is not None]
+        # skip a count that cannot finish warm-up + 2 steps in what is left of the budget, or once adding threads made it slower
+        if done_ and (left < 3.5 * done_[-1][1] or done_[-1][1] > 1.3 * min(t[1] for t in done_)):
+            tried.append((th, None, 0))
+            continue
+        torch.set_num_threads(th)
         t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {'value': B / med, 'unit': 'patch-pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{len(times)} steps of B={B} 13x128x128 fwd+Tversky+bwd+SGD, fp32 stock torch.nn '
-                      f'assembly of the reference graph (oracle.build_torch_baseline, forward pinned to the golden logits by '
-                      f'tests/test_oracle_cpu.py), median; {torch.get_num_threads()} threads = all {ncores} host CPUs ({_cpu_model()})'}
+        step()                                        # warm-up (oneDNN primitive creation for this thread count)
+        warm = time.perf_counter() - t0
+        times = []
+        while len(times) < 2 and (time.perf_counter() - t_start) < seconds_budget and (len(times) < 1 or warm < 6.0):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        tried.append((th, times[len(times) // 2] if times else warm, len(times)))
+    done = [t for t in tried if t[1] is not None]
+    best = min(done, key=lambda t: t[1])
+    listing = ', '.join(f'{th} threads: ' + (f'{B / t:.2f} pairs/s ({n} steps)' if t is not None else 'skipped (budget / already slower with fewer threads)') for th, t, n in tried)
+    return {'value': B / best[1], 'unit': 'patch-pairs/s', 'cores': best[0], 'kind': 'port',
+            'sample': f'B={B} 13x128x128 fwd+Tversky+bwd+SGD steps, fp32 stock torch.nn assembly of the reference graph '
+                      f'(oracle.build_torch_baseline, pinned to the golden logits by tests/test_oracle_cpu.py), median per thread count, '
+                      f'best reported; host has {ncores} usable CPUs ({_cpu_model()}); {listing}'}
 
 
 # ---------------------------------------------------------------------------------------------- committed profile artefacts
@@ -322,6 +345,7 @@ def main():
         eng.prof_pick = i % n_dom if n_dom else None          # step i brackets the (i mod n)-th launch of the dominant kernel
         picks.append(eng.prof_pick)
         loss = ts.step(x1, x2, lbl)
+    enqueue_s = time.perf_counter() - t0                       # host time to enqueue K steps (no sync inside the loop)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -376,6 +400,7 @@ def main():
                        'parallelism': f'dp{world}', 'precision': args.precision, 'inputs': 'resident in HBM'},
             'step_mfma_frac': value * FLOP_PER_PAIR_FWD_BWD / (world * peak),
             'final_loss': loss_val,
+            'host_enqueue_ms_per_step': enqueue_s / args.steps * 1e3,
             'roofline': roofline,
         }
         hb = pmc_step_bytes(args.precision)
