@@ -936,8 +936,10 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
     if (want == BDN_WG_DMA2 && dma_ok) p.variant = BDN_WG_DMA2;
     // the simple kernel (first layer / 8x8 maps / f32) has no software pipeline: it hides latency with a second block per CU
     int blocks = (flags >> 16) & 0x1fff;
-    if (blocks == 0) blocks = 256;                          // ~one block per CU: the kernel runs beside the dgrad chain on a second stream, so
-                                                            // a smaller partial-sum footprint beats more parallelism (A/B: 512 -> 256 = -2.7 % step)
+    if (blocks == 0) blocks = 128;                          // HALF the CUs: the GEMM runs beside the dz chain on a second stream, and two MFMA kernels
+                                                            // sharing a CU lose throughput -- with 128 blocks (16 per XCD) the chain's convolutions
+                                                            // always find free CUs and the partial-sum traffic halves again (A/B inside the step:
+                                                            // 512 -> 256 = -2.7 %, 256 -> 128 = -2.6 %; 112 / 144 / 96: +3.5 % / +3.7 % / +4 %)
     int S = ((p.variant == BDN_WG_SIMPLE ? WG_SIMPLE_MULT : 1) * blocks + tiles - 1) / tiles;
     if (S > p.g.n_mtiles) S = p.g.n_mtiles;
     if (S < 1) S = 1;
@@ -961,7 +963,11 @@ extern "C" size_t bdn_wgrad_workspace_bytes(int N, int H, int W, int Cout, int C
     const size_t a = bdn_wgrad_workspace_bytes_ex(BDN_F32, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
     const size_t b = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
     const size_t c = bdn_wgrad_workspace_bytes_ex(BDN_BF16X3, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, 0);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    // bdn_conv3x3_wgrad_bnbwd (first layer, end of backward) plans its own, larger grid
+    const size_t d = Cin <= 32 ? bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, Cout, Cin, 0, imgs_per_group, BDN_IN_PLAIN, BDN_WG_FLAGS(0, 0, 256)) : 0;
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    return m > d ? m : d;
 }
 
 template <typename T, int TH, int TW, int TI, bool KSPLIT>
@@ -1060,7 +1066,8 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
     if (!bdn_conv3x3_wgrad_bnbwd_supported(dtype, N, H, W, Cout, C0, imgs_per_group))
         BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: only bf16, Cout=64, C0=16, 8x16 tiles (got dtype %d Cout %d C0 %d)", dtype, Cout, C0);
     if (ldA < 64 || ldA % 8 || Cin_real <= 0 || Cin_real > 16) BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: bad ldA=%d / Cin_real=%d", ldA, Cin_real);
-    const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, 0, imgs_per_group, BDN_IN_PLAIN, 0);
+    // runs at the very end of backward on the MAIN stream (two blocks per CU, nothing of the chain left): its own grid of 512
+    const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, 0, imgs_per_group, BDN_IN_PLAIN, BDN_WG_FLAGS(0, 0, 256));
     WgFirstArgs a;
     a.dA = (const bf16s*)dA; a.ldA = ldA; a.z = (const bf16s*)z; a.bn = bn; a.sums = sums; a.x = (const bf16s*)in0;
     a.partial = partial; a.N = N; a.H = H; a.W = W; a.imgs_per_group = imgs_per_group;

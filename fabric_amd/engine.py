@@ -123,12 +123,13 @@ class Workspace:
                 n_stats = max(n_stats, 2 * lib.bdn_enc_skip_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(eng.dt, n, hk, wk, L.cout, ipg) // 4)
             if not eng.x3:                            # bf16x3 sizes its doubled-operand workspace per call (split_buf)
-                n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes_ex(eng.dt, n, hk, wk, L.cout, L.cin, 0, ipg, IN_PLAIN, 0) // 4)
+                for blocks in (0, 512):               # 512: head room for A/B runs of engine.wgrad_blocks (any grid up to 512 fits)
+                    n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes_ex(eng.dt, n, hk, wk, L.cout, L.cin, 0, ipg, IN_PLAIN, wg_flags(3, 0, blocks)) // 4)
         self.stats = f32(n_stats)
         self.bnws = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device=device)
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
-        self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, 0) // 4
+        self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, 256)) // 4
         self.n_act = max(self.z[L.name].numel() for L in eng.layers if L.name.endswith('a'))
         self._bwd = None
         self._split = {}
@@ -191,9 +192,13 @@ class BiDateEngine:
         self.fuse_head_bwd = True       # A/B switch: d4b's BatchNorm backward recomputes the classifier's data gradient from dlogits
         self.fuse_first_wgrad = True    # A/B switch: the first conv's BatchNorm backward inside its weight-gradient GEMM (bf16 only)
         self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
-        self.wgrad_dma = True           # A/B switch: relu(bn(z)) of the 'a' convs is materialised once on the weight-gradient stream and
-                                        # the following conv's weight-gradient GEMM takes the LDS-DMA kernel (plain operands only)
+        self.wgrad_dma = False          # A/B switch: relu(bn(z)) of the 'a' convs is materialised once on the weight-gradient stream and
+                                        # the following conv's weight-gradient GEMM takes the LDS-DMA kernel (plain operands only).
+                                        # The 'a' layers (plain inputs) take that kernel anyway; for the 'b' layers the extra HBM pass
+                                        # costs the step more than the faster GEMM returns (6.37 vs 6.29 ms), so they keep
+                                        # BatchNorm-on-load in the register-staged kernel
         self.wgrad_kernel = 0           # A/B: per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
+        self.wgrad_blocks = 0           # A/B: per-call target grid of the weight-gradient GEMM (0 = default: one block per CU)
         self.wgrad_sched = 0            # how the weight-gradient GEMMs are placed beside the dz chain (both are MFMA-bound; two
                                         # MFMA kernels sharing the chip LOSE throughput, an MFMA kernel beside an HBM-bound one gains):
                                         #   0  released as soon as their dz exists (overlap whatever the chain runs next)
@@ -454,7 +459,7 @@ class BiDateEngine:
                 return
             wk_ = self.wgrad_kernel
             if mode == IN_BNRELU and self.wgrad_dma and \
-                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_)) in (WG_DMA, WG_DMA2):
+                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_, self.wgrad_blocks)) in (WG_DMA, WG_DMA2):
                 # the DMA kernel's operands never pass through registers: write a = relu(bn(z)) once (instead of deriving it in
                 # each of the Cout/64 column-tile blocks of the GEMM) and hand the GEMM a plain tensor
                 act = sc['act'][:in0.numel()]
@@ -464,7 +469,7 @@ class BiDateEngine:
                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
             name = None
             if self.prof is not None:
-                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_))
+                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_, self.wgrad_blocks))
                 if v in (WG_DMA, WG_DMA2):
                     name = f'wgrad6_kernel<{3 if v == WG_DMA else 2}>'
                 elif v == WG_PIPE:
@@ -480,13 +485,13 @@ class BiDateEngine:
                     if self._prof_seen - 1 != self.prof_pick:
                         name = None
             if name is None:
-                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(3, wk_), stp)
+                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(3, wk_, self.wgrad_blocks), stp)
                 return
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(1, wk_), stp)
+            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(1, wk_, self.wgrad_blocks), stp)
             e1.record()
-            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(2, wk_), stp)
+            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(2, wk_, self.wgrad_blocks), stp)
             self.prof.append((name, 2.0 * n * hk * wk * L.cout * 9 * (c0 + c1), e0, e1))
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
