@@ -132,6 +132,8 @@ class Workspace:
         self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, 256)) // 4
         self.n_act = max(self.z[L.name].numel() for L in eng.layers if L.name.endswith('a'))
         self._bwd = None
+        self.act = {}              # data_ptr of an 'a' conv's z -> its materialised relu(bn(z)) (written by the following conv's forward)
+        self.act_valid = set()
         self._split = {}
         self._outc_ws = None
         self.logits = None
@@ -197,6 +199,9 @@ class BiDateEngine:
                                         # The 'a' layers (plain inputs) take that kernel anyway; for the 'b' layers the extra HBM pass
                                         # costs the step more than the faster GEMM returns (6.37 vs 6.29 ms), so they keep
                                         # BatchNorm-on-load in the register-staged kernel
+        self.fwd_writes_act = False     # A/B switch (bf16; measured +0.6 % step time: the stores cost the chain what the faster GEMM saves beside it): the training forward of a 'b' conv also writes the relu(bn(z)) tile it stages
+                                        # (bdn_conv3x3_act), so that layer's weight-gradient GEMM gets a plain operand (LDS-DMA kernel)
+                                        # without any extra pass
         self.wgrad_kernel = 0           # A/B: per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self.wgrad_blocks = 0           # A/B: per-call target grid of the weight-gradient GEMM (0 = default: one block per CU)
         self.wgrad_sched = 0            # how the weight-gradient GEMMs are placed beside the dz chain (both are MFMA-bound; two
@@ -215,12 +220,13 @@ class BiDateEngine:
         _lib.load()                # fail loudly now if the HIP extension is missing
 
     # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
-    def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg):
+    def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg, act=False):
         """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to: asked from the library's own dispatcher."""
-        return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg).decode()
+        return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg,
+                                               1 if act else 0).decode()
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
-        name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
+        name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg, act=fn == 'bdn_conv3x3_act') if self.prof is not None else None
         if self.prof is None or (self.prof_filter is not None and name != self.prof_filter):
             call(fn, *args)
             return
@@ -310,10 +316,21 @@ class BiDateEngine:
             sp = ws.split_buf('a', n * hk * wk * 2 * (c0 + c1))
             call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
             in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
-        self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
-                         self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
-                         ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
-                         n, hk, wk, L.cout, st)
+        if training and in_mode == IN_BNRELU and self.fwd_writes_act and not self.x3 and \
+                _lib.load().bdn_conv3x3_act_supported(self.mdt, n, hk, wk, c0, L.cout, ipg):
+            act = ws.act.get(in0.data_ptr())
+            if act is None:
+                act = ws.act[in0.data_ptr()] = torch.empty_like(in0)
+            self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
+                             self.mdt, ptr(in0), c0, ptr(in_bn), ipg, ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats),
+                             ptr(act), n, hk, wk, L.cout, st, fn='bdn_conv3x3_act')
+            ws.act_valid.add(in0.data_ptr())
+        else:
+            ws.act_valid.discard(in0.data_ptr())
+            self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
+                             self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
+                             ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
+                             n, hk, wk, L.cout, st)
         bn = ws.bn[L.name]
         G = n // ipg
         if training:
@@ -458,6 +475,8 @@ class BiDateEngine:
                      ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, 3, stp)
                 return
             wk_ = self.wgrad_kernel
+            if mode == IN_BNRELU and in0.data_ptr() in ws.act_valid:
+                in0, mode, in_bn = ws.act[in0.data_ptr()], IN_PLAIN, None      # written by this layer's forward (bdn_conv3x3_act)
             if mode == IN_BNRELU and self.wgrad_dma and \
                     lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_, self.wgrad_blocks)) in (WG_DMA, WG_DMA2):
                 # the DMA kernel's operands never pass through registers: write a = relu(bn(z)) once (instead of deriving it in

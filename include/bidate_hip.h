@@ -65,9 +65,18 @@ int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 const void* w, const float* bias, void* out, float* stats_partial,
                 int N, int H, int W, int Cout, void* stream);
 int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group);
-/* Name of the kernel instantiation bdn_conv3x3 runs for a shape, e.g. "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false>"
- * (the rocprofv3 name with `unsigned short` spelled bf16); "" for an unsupported shape.  Thread-local buffer. */
-const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group);
+/* bdn_conv3x3 with a BatchNorm+ReLU input (in_mode BDN_IN_BNRELU, one source) that ALSO writes the post-activation tensor
+ * it stages, act_out [N,H,W,C0] = relu(in0*scale + shift) in the storage type (models/unet_parts.py:14-15) -- the operand of
+ * this layer's weight gradient, materialised at the cost of the stores only.  bf16, the large shape classes only
+ * (bdn_conv3x3_act_supported); BDN_E_SHAPE otherwise. */
+int bdn_conv3x3_act_supported(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group);   /* 1: bdn_conv3x3_act runs this shape */
+int bdn_conv3x3_act(int dtype, const void* in0, int C0, const float* in_bn, int imgs_per_group,
+                    const void* w, const float* bias, void* out, float* stats_partial, void* act_out,
+                    int N, int H, int W, int Cout, void* stream);
+/* Name of the kernel instantiation bdn_conv3x3 (act = 0) / bdn_conv3x3_act (act = 1) runs for a shape, e.g.
+ * "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false>" (the rocprofv3 name with `unsigned short` spelled bf16);
+ * "" for an unsupported shape.  Thread-local buffer. */
+const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group, int act);
 
 /* Data gradient of nn.Conv2d(ci,co,3,padding=1) (autograd of models/unet_parts.py:13,16) with the BatchNorm-backward
  * statistics of the PRODUCING layer fused into the epilogue: dz [N,H,W,C0] x rotated filter image w_dgrad ->

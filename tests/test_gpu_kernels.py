@@ -249,6 +249,46 @@ def test_bnrelu_materialised(prec, shape):
         _lib.call('bdn_bnrelu', dt, z_d.data_ptr(), bn_d.data_ptr(), ipg, out.data_ptr(), N, H, W, C + 1, st())
 
 
+@pytest.mark.parametrize('case', [(4, 32, 32, 64, 64, 2), (2, 37, 50, 64, 64, 1), (16, 64, 64, 128, 128, 8), (32, 45, 64, 256, 256, 16),
+                                  (32, 40, 60, 64, 128, 16)])
+def test_conv3x3_act_writes_the_staged_activation(case):
+    """bdn_conv3x3_act == bdn_conv3x3 (same output and statistics, bit for bit) + the relu(bn(in0)) tensor it staged, equal to
+    bdn_bnrelu's (the operand of the layer's weight gradient, models/unet_parts.py:14-16); every pixel written exactly once,
+    ragged tiles included."""
+    N, H, W, Cin, Cout, ipg = case
+    lib = _lib.load()
+    dt, td = DT['bf16']
+    assert lib.bdn_conv3x3_act_supported(dt, N, H, W, Cin, Cout, ipg) == 1
+    x = to_nhwc('bf16', rnd('bf16', _rand((N, Cin, H, W), 401)))
+    bn_d = dev(bn_table(N // ipg, Cin, 402))
+    w = rnd('bf16', _rand((Cout, Cin, 3, 3), 403) * 0.1)
+    wf, _ = pack_w('bf16', w, Cin)
+    bias = dev(_rand((Cout,), 404))
+    nt = lib.bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
+    outs = []
+    for act in (False, True):
+        out = torch.full((N, H, W, Cout), float('nan'), dtype=td, device='cuda')
+        stats = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+        a = torch.full((N, H, W, Cin), float('nan'), dtype=td, device='cuda')
+        if act:
+            _lib.call('bdn_conv3x3_act', dt, x.data_ptr(), Cin, bn_d.data_ptr(), ipg, wf.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                      stats.data_ptr(), a.data_ptr(), N, H, W, Cout, st())
+        else:
+            _lib.call('bdn_conv3x3', dt, x.data_ptr(), Cin, None, 0, IN_BNRELU, bn_d.data_ptr(), ipg, wf.data_ptr(), bias.data_ptr(),
+                      out.data_ptr(), stats.data_ptr(), N, H, W, Cout, st())
+            _lib.call('bdn_bnrelu', dt, x.data_ptr(), bn_d.data_ptr(), ipg, a.data_ptr(), N, H, W, Cin, st())
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), stats.cpu(), a.cpu()))
+    for got, want, what in zip(outs[1], outs[0], ('output', 'statistics', 'activation')):
+        assert torch.isfinite(got.float()).all(), what
+        assert torch.equal(got, want), what
+    assert lib.bdn_conv3x3_act_supported(dt, N, 8, 8, Cin, Cout, ipg) == 0        # 8x8 maps: no activation-writing variant
+    assert lib.bdn_conv3x3_act_supported(DT['fp32'][0], N, H, W, Cin, Cout, ipg) == 0
+    with pytest.raises(RuntimeError):
+        _lib.call('bdn_conv3x3_act', dt, x.data_ptr(), Cin, bn_d.data_ptr(), ipg, wf.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                  stats.data_ptr(), a.data_ptr(), N, 8, 8, Cout, st())
+
+
 @pytest.mark.parametrize('prec', PRECS)
 def test_fuse_product(prec):
     B, H, W, C = 3, 10, 12, 64

@@ -164,18 +164,21 @@ def test_first_layer_fused_weight_gradient_equals_two_kernel_path(golden_dir, na
 
 @pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
 def test_dma_weight_gradient_switch_leaves_every_gradient_unchanged(golden_dir, name):
-    """engine.wgrad_dma (bf16): relu(bn(z)) materialised once + the LDS-DMA weight-gradient kernel instead of BatchNorm on
-    load inside the register-staged kernel -- same operands, same split plan, same accumulation order: bit-equal gradients."""
+    """engine.fwd_writes_act / engine.wgrad_dma (bf16): relu(bn(z)) materialised (by the forward conv that stages it, or by a
+    separate pass) + the LDS-DMA weight-gradient kernel, instead of BatchNorm on load inside the register-staged kernel -- same
+    operands, same split plan, same accumulation order: bit-equal gradients."""
     g, c, x1, x2, lbl = _load(golden_dir, name)
     grads = {}
-    for dma in (False, True):
+    for dma in (False, True, 'fwd'):
         model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
-        model.engine().wgrad_dma = dma
+        model.engine().wgrad_dma = dma is True                  # True: separate bdn_bnrelu pass on the weight-gradient stream
+        model.engine().fwd_writes_act = dma == 'fwd'            # 'fwd': the forward conv writes the activation it stages (default)
         _tversky_torch(model(x1, x2), lbl).backward()
         torch.cuda.synchronize()
         grads[dma] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+        assert torch.equal(grads['fwd'][k], grads[False][k]), k
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
