@@ -51,6 +51,7 @@ SIGNATURES = {
     'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_enc_skip_bwd_ex': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_enc_skip_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_outc_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -199,6 +199,8 @@ class BiDateEngine:
                                         # The 'a' layers (plain inputs) take that kernel anyway; for the 'b' layers the extra HBM pass
                                         # costs the step more than the faster GEMM returns (6.37 vs 6.29 ms), so they keep
                                         # BatchNorm-on-load in the register-staged kernel
+        self.enc_two_pass = False       # A/B switch: the encoder's skip / unpool backward as sums pass + fused apply pass (dA never written:
+                                        # 22 % fewer bytes, bit-identical dz -- but the kernel's argmax / product work runs twice: +1.9 % step)
         self.fwd_writes_act = False     # A/B switch (bf16; measured +0.6 % step time: the stores cost the chain what the faster GEMM saves beside it): the training forward of a 'b' conv also writes the relu(bn(z)) tile it stages
                                         # (bdn_conv3x3_act), so that layer's weight-gradient GEMM gets a plain operand (LDS-DMA kernel)
                                         # without any extra pass
@@ -648,12 +650,25 @@ class BiDateEngine:
                 dF_ptr, ldF = ptr(dF5), ck
             else:
                 dF_ptr, ldF = ptr(dcat[k]), dcat[k].shape[3]
-            dAb = e(2 * B, hk, wk, ck)
             fuse = self.fuse_bn_bwd_stats
-            call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
-                 ptr(dP), ptr(dAb), ptr(ws.stats) if fuse else None, B, hk, wk, ck, st)
             rows_b = _lib.load().bdn_enc_skip_bwd_rows(self.dt, B, hk, wk, ck) if fuse else 0
-            dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
+            if fuse and self.enc_two_pass:
+                # dA of the skip / unpool backward is never written: one pass for the BatchNorm-backward sums, one that
+                # recomputes dA and writes dz (the skip gradient, the pooled gradient and z are read twice instead of dA being
+                # written once and read once: 22 % fewer bytes)
+                dAb = None
+                dzb = e(2 * B, hk, wk, ck)
+                call('bdn_enc_skip_bwd_ex', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
+                     ptr(dP), None, ptr(ws.stats), None, 1, B, hk, wk, ck, st)
+                call('bdn_bn_bwd_finalize', ptr(ws.bn[Lb.name]), 2, ck, ptr(ws.stats), rows_b, 1, ptr(sc['sums']),
+                     ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
+                call('bdn_enc_skip_bwd_ex', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
+                     ptr(dP), ptr(dzb), None, ptr(sc['sums']), 2, B, hk, wk, ck, st)
+            else:
+                dAb = e(2 * B, hk, wk, ck)
+                call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
+                     ptr(dP), ptr(dAb), ptr(ws.stats) if fuse else None, B, hk, wk, ck, st)
+                dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
             if not late:
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
             dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)

@@ -217,6 +217,12 @@ int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const fl
 /* bs_partial: NULL, or f32 [2][bdn_enc_skip_bwd_rows(dtype,B,H,W,C)][2][C] receiving the BatchNorm-backward partial
  * sums of the layer (per block: sum g, sum g*z; date 1 rows then date 2 rows) -> bdn_bn_bwd_apply(raw_moment = 1). */
 int bdn_enc_skip_bwd_rows(int dtype, int B, int H, int W, int C);
+/* The same in two passes that never write dA: mode 1 = the partial sums only (out unused), then bdn_bn_bwd_finalize(G = 2,
+ * raw_moment = 1) turns them into `sums` [2][2][C], then mode 2 recomputes dA and writes out = dz = BatchNorm+ReLU backward
+ * of it (bit for bit what mode 0 + bdn_bn_bwd_apply give; 22 % fewer HBM bytes).  mode 0 = bdn_enc_skip_bwd. */
+int bdn_enc_skip_bwd_ex(int dtype, const void* dF, int ldF, const void* z, const float* bn,
+                        const void* dP, void* out, float* bs_partial, const float* sums, int mode,
+                        int B, int H, int W, int C, void* stream);
 
 /* ---- outconv: nn.Conv2d(64, n_classes, 1), models/unet_parts.py:86 ----
  * z: [B,H,W,C] raw output of up4's second conv, bn: [1][4][C]; w: [ncls][C] f32, b: [ncls];

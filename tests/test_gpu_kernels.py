@@ -382,6 +382,26 @@ def test_enc_skip_bwd(prec, case):
     # multiplied by the producer's own ReLU mask [a > 0] in the very next step (bn_bwd), so compare there.
     live = (a.detach() > 0).float()
     assert_close('enc_skip_bwd', from_nhwc(out) * live, ref * live, 1e-6 if prec == 'fp32' else 8e-3)
+    # two passes that never write dA (mode 1: sums only, mode 2: recompute + BatchNorm backward) == mode 0 + bdn_bn_bwd_apply, bit for bit
+    lib = _lib.load()
+    sums = torch.empty(2, 2, C, device='cuda')
+    dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    scratch = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device='cuda')
+    dz_ref = torch.full((2 * B, H, W, C), float('nan'), dtype=td, device='cuda')
+    _lib.call('bdn_bn_bwd_apply', dt, out.data_ptr(), C, z_d.data_ptr(), bn_d.data_ptr(), B, 2 * B, H, W, C, part.data_ptr(), rows, 1,
+              sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz_ref.data_ptr(), scratch.data_ptr(), st())
+    part2 = torch.full((2, rows, 2, C), float('nan'), device='cuda')
+    _lib.call('bdn_enc_skip_bwd_ex', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
+              dP_d.data_ptr() if pooled else None, None, part2.data_ptr(), None, 1, B, H, W, C, st())
+    sums2, dg2, db2 = torch.empty(2, 2, C, device='cuda'), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    _lib.call('bdn_bn_bwd_finalize', bn_d.data_ptr(), 2, C, part2.data_ptr(), rows, 1, sums2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
+              scratch.data_ptr(), st())
+    dz = torch.full((2 * B, H, W, C), float('nan'), dtype=td, device='cuda')
+    _lib.call('bdn_enc_skip_bwd_ex', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
+              dP_d.data_ptr() if pooled else None, dz.data_ptr(), None, sums2.data_ptr(), 2, B, H, W, C, st())
+    torch.cuda.synchronize()
+    assert torch.equal(part2, part) and torch.equal(sums2, sums) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    assert torch.isfinite(dz.float()).all() and torch.equal(dz, dz_ref)
 
 
 # ------------------------------------------------------------------ classifier
