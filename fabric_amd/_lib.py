@@ -43,6 +43,9 @@ SIGNATURES = {
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_conv3d_num_mtiles': (_i, [_i, _i, _i, _i]),
+    'bdn_conv3d': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'bdn_conv3d_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_split_pack': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     'bdn_bnrelu': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -23,6 +23,10 @@ struct WgradArgs {
     int N, H, W;
     int tiles_y, tiles_x, n_mtiles;
     int S, per_split, n_cot, n_cit;
+    // 3x3x3 mode (bdn_conv3d_wgrad): the N images are depth slices of N/Dz samples; this launch is depth tap kd = dshift + 1, i.e.
+    // dz of slice n pairs with the activation slice n + dshift, and chunks whose partner slice lies outside the sample are skipped
+    // (8x16 tiles of one slice only).  Dz = 0: 2-D.
+    int Dz, dshift;
 };
 
 template <typename T, int TH, int TW, int TI>
@@ -92,14 +96,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     {                                                                                                   \
         const int tx_ = (q_) % a.tiles_x, ty_ = ((q_) / a.tiles_x) % a.tiles_y, ib_ = (q_) / (a.tiles_x * a.tiles_y); \
         const int n0_ = ib_ * TI, y0_ = ty_ * TH, x0_ = tx_ * TW;                                       \
+        const bool dlive_ = a.Dz == 0 || (unsigned)(n0_ % a.Dz + a.dshift) < (unsigned)a.Dz;           \
         grp_next = n0_ / a.imgs_per_group; p_ok = 0;                                                    \
         _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
             const int u = tid + i * 256, pix = u / UPP;                                                  \
             const int xx = pix % TL::PW, t_ = pix / TL::PW, yy = t_ % TL::PH, ti = t_ / TL::PH;          \
             const int n = n0_ + ti, y = y0_ + yy - 1, x = x0_ + xx - 1;                                  \
-            const bool ok_ = u < TL::NPIX * UPP && sub_ok && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
+            const bool ok_ = dlive_ && u < TL::NPIX * UPP && sub_ok && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
             p_ok |= (ok_ ? 1u : 0u) << i;                                                                \
-            if (ok_) preg[i] = *reinterpret_cast<const uint4*>(src + ((size_t)(n * a.H + y) * a.W + x) * Csrc + cs + sub_e); \
+            if (ok_) preg[i] = *reinterpret_cast<const uint4*>(src + ((size_t)((n + a.dshift) * a.H + y) * a.W + x) * Csrc + cs + sub_e); \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < NDU; i++) {                                                \
             const int slot = (tid + i * 256) / UPP;                                                      \
@@ -536,6 +541,8 @@ __global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
     const int q_end = min(a.n_mtiles, q_begin + a.per_split);
     int lq = q_begin;                                          // DMA cursor: chunk index and its tile coordinates
     int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
+    int ldep = a.Dz ? ln % a.Dz : 0;                           // 3x3x3 mode: depth index of slice ln inside its sample
+    const long dslice = (long)a.dshift * a.H * a.W;            // pixels between a dz slice and its partner activation slice
     // per-chunk state of the DMA issue (set by W6_BEGIN, used by the W6_P / W6_D pieces spread over the MFMA rows)
     u32x4_t rs_p = {0, 0, 0, 0}, rs_d = {0, 0, 0, 0};
     int cy0 = 0, cx0 = 0; bool clive = false;
@@ -544,11 +551,13 @@ __global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
 
 #define W6_BEGIN(wb_)                                                                                    \
     {                                                                                                   \
-        clive = lq < q_end; cy0 = lty * 8; cx0 = ltx * 16; cwb = (wb_);                                  \
+        const bool inside_ = lq < q_end;                                                                \
+        clive = inside_ && (a.Dz == 0 || (unsigned)(ldep + a.dshift) < (unsigned)a.Dz);                  \
+        cy0 = lty * 8; cx0 = ltx * 16; cwb = (wb_);                                                      \
         const long pixbase_ = clive ? (long)(ln * a.H + cy0) * a.W + cx0 : 0;                           \
-        rs_p = raw_rsrc(src + (pixbase_ - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS);                        \
+        rs_p = raw_rsrc(src + (pixbase_ + (clive ? dslice : 0) - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS); \
         rs_d = raw_rsrc(dzp + pixbase_ * a.Cout * 2, Wg6::NUM_RECORDS);                                 \
-        if (clive) { lq++; if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; } } } \
+        if (inside_) { lq++; if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (++ldep == a.Dz) ldep = 0; } } } \
     }
 #define W6_P(i_)                                                                                         \
     {                                                                                                   \
@@ -857,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_first_kernel(WgFirstArgs a) {
 // leave as 36 contiguous bytes of the reference's OIHW layout.
 template <int SL>
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                    int S, int Cout, int Cin, int Cin_real) {
+                                    int S, int Cout, int Cin, int Cin_real, int ostride, int ooff) {
     constexpr int PAIRS = 256 / SL;
     __shared__ float sm[SL][PAIRS][9];
     const size_t plane = (size_t)Cout * Cin;
@@ -882,13 +891,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
             for (int t = 0; t < 9; t++) {
                 float v = acc[t];
                 for (int k = 1; k < SL; k++) v += sm[k][pl][t];
-                dw[((size_t)co * Cin_real + ci) * 9 + t] = v;
+                dw[((size_t)co * Cin_real + ci) * ostride + ooff + t] = v;      // OIHW (stride 9) or tap kd of OIDHW (stride 27, offset 9 kd)
             }
         }
     }
 }
 
-static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout, int Cin, int Cin_real, hipStream_t st) {
+static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout, int Cin, int Cin_real, hipStream_t st,
+                                int ostride = 9, int ooff = 0) {
     const size_t plane = (size_t)Cout * Cin;
     // split lanes give the small filters some parallelism -- up to ~256 blocks, never more lanes than splits.  More, thinner
     // blocks (the first version went to 2048) read 64-byte pieces of every partial tile: the same speed alone, but inside
@@ -897,11 +907,11 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
     while (SL < 16 && SL * 2 <= S && plane / (256 / (SL * 2)) < 256) SL *= 2;
     const unsigned grid = (unsigned)((plane + 256 / SL - 1) / (256 / SL));
     switch (SL) {
-        case 1: hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
-        case 2: hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
-        case 4: hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
-        case 8: hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
-        default: hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real); break;
+        case 1: hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real, ostride, ooff); break;
+        case 2: hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real, ostride, ooff); break;
+        case 4: hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real, ostride, ooff); break;
+        case 8: hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real, ostride, ooff); break;
+        default: hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(grid), dim3(256), 0, st, partial, dw, S, Cout, Cin, Cin_real, ostride, ooff); break;
     }
 }
 
@@ -1021,6 +1031,7 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     a.partial = partial; a.N = N; a.H = H; a.W = W;
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles;
     a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit;
+    a.Dz = 0; a.dshift = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = BDN_OK;
     if (!(phases & 1)) {
@@ -1086,4 +1097,41 @@ extern "C" int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cou
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || imgs_per_group <= 0) return 0;
     if (dtype == BDN_BF16X3) return wgrad_plan(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags).variant;
     return wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags).variant;
+}
+
+// ---- weight gradient of the 3x3x3 convolution (bdn_conv3d): dw[co][ci][kd][kh][kw], f32 OIDHW.
+// Three runs of the 2-D split-K GEMM, one per depth tap: dz slice n against the activation slice n + kd - 1 (chunks whose partner
+// lies outside the sample are skipped), each reduced into its 9 of the 27 taps.  Plain inputs only (materialise relu(bn(z)) with
+// bdn_bnrelu first).  partial: bdn_wgrad_workspace_bytes_ex(dtype, N*D, H, W, Cout, C, 0, 1, BDN_IN_PLAIN, 0) bytes.
+extern "C" int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void* in, int C,
+                                float* partial, float* dw_oidhw, int Cin_real, int N, int D, int H, int W, void* stream) {
+    if (!dz || !in || !partial || !dw_oidhw) BDN_FAIL(BDN_E_ARG, "conv3d_wgrad: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: bad N=%d D=%d H=%d W=%d", N, D, H, W);
+    if (Cout <= 0 || Cout % 64 || C <= 0 || C % 16 || Cin_real <= 0 || Cin_real > C)
+        BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: Cout=%d must be a multiple of 64, C=%d of 16, Cin_real=%d <= C", Cout, C, Cin_real);
+    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3d_wgrad: bad dtype %d (bf16 / f32)", dtype);
+    const int NS = N * D;
+    const WgPlan p = wgrad_plan(dtype, NS, H, W, Cout, C, 0, 1 /* one slice per tile */, BDN_IN_PLAIN, 0);
+    if (p.g.TI != 1) BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: internal plan error");
+    WgradArgs a;
+    a.dz = dz; a.Cout = Cout; a.in0 = in; a.in1 = nullptr; a.C0 = C; a.C1 = 0; a.in_bn = nullptr; a.imgs_per_group = 1;
+    a.partial = partial; a.N = NS; a.H = H; a.W = W;
+    a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles;
+    a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit;
+    a.Dz = D;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int kd = 0; kd < 3; kd++) {
+        a.dshift = kd - 1;
+        int rc;
+        if (dtype == BDN_BF16) {
+            if (p.variant == BDN_WG_DMA) rc = launch_wgrad6<3>(a, st);
+            else rc = p.ksplit ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 16, 1, false>(a, st);
+        } else {
+            rc = p.ksplit ? launch_wgrad<float, 8, 16, 1, true>(a, st) : launch_wgrad<float, 8, 16, 1, false>(a, st);
+        }
+        if (rc) return rc;
+        launch_wgrad_reduce(partial, dw_oidhw, p.S * (p.ksplit ? 2 : 1), Cout, C, Cin_real, st, 27, 9 * kd);
+        BDN_CHECK_LAUNCH("conv3d_wgrad_reduce");
+    }
+    return BDN_OK;
 }

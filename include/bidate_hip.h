@@ -87,6 +87,24 @@ int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad,
                          const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
                          int N, int H, int W, int Cout, void* stream);
 
+/* ---- 3x3x3 convolution, stride 1, zero padding 1 (BASELINE configs[3]: the multi-date 3-D U-Net stack) ----
+ * The reference tree holds NO source for that model (UNetLSTM/ is an empty sub-module, README.md:5): parity is UNPINNED, the
+ * oracle is torch.nn.functional.conv3d.  Implicit GEMM with K = 27 Cin on the 2-D kernels: tensors are [N,D,H,W,C] (the D
+ * slices of a sample are consecutive NHWC images), a 3x3x3 window is three 3x3 windows on slices d-1, d, d+1 = three sources
+ * of one reduction, a slice outside the sample is a zero mask.  No depth padding, no im2col.
+ *   w      bdn_pack_weights image (wf) of the OIHW view [Cout][3 C][3][3] whose input channel kd*C + c holds w3d[co][c][kd][.][.]
+ *          (data gradient: the same entry point on dz with the view [C][3 Cout][3][3], channel s*Cout + co = w3d[co][c][2-s][2-kh][2-kw])
+ *   in_mode / in_bn / stats_partial / bias as in bdn_conv3x3; imgs_per_group counts samples;
+ *   stats_partial rows: bdn_conv3d_num_mtiles(N, D, H, W).  dtype: BDN_BF16 or BDN_F32.
+ * bdn_conv3d_wgrad: dw [Cout][Cin_real][3][3][3] f32 from dz [N,D,H,W,Cout] and the PLAIN input [N,D,H,W,C];
+ *   partial: bdn_wgrad_workspace_bytes_ex(dtype, N*D, H, W, Cout, C, 0, 1, BDN_IN_PLAIN, 0) bytes. */
+int bdn_conv3d_num_mtiles(int N, int D, int H, int W);
+int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const float* in_bn, int imgs_per_group,
+               const void* w, const float* bias, void* out, float* stats_partial,
+               int N, int D, int H, int W, int Cout, void* stream);
+int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void* in, int C,
+                     float* partial, float* dw_oidhw, int Cin_real, int N, int D, int H, int W, void* stream);
+
 /* ---- bf16x3 operand split (dtype BDN_BF16X3 of bdn_conv3x3 / bdn_conv3x3_dgrad_bs / bdn_conv3x3_wgrad* / bdn_pack_weights) ----
  * The 1e-3-parity setting at matrix-core speed: tensors stay float32; a GEMM operand x is fed as hi = bf16(x) and
  * lo = bf16(x - hi) and a product keeps a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (float32 accumulate).  bdn_split_pack builds the
