@@ -184,7 +184,7 @@ def host_fed_leg(ts, dev, B, C, S, steps, warmup, resident_ms):
         x1 = torch.randn(B, C, S, S, generator=g)
         pool.append((x1.pin_memory(), (x1 + 0.3 * torch.randn(B, C, S, S, generator=g)).pin_memory(),
                      (torch.rand(B, S, S, generator=g) < 0.1).to(torch.uint8).pin_memory()))
-    feeder = DeviceFeeder(dev, depth=2)
+    feeder = DeviceFeeder(dev)
 
     def batches(n):
         for i in range(n):
@@ -200,7 +200,7 @@ def host_fed_leg(ts, dev, B, C, S, steps, warmup, resident_ms):
     nbytes = sum(t.numel() * t.element_size() for t in pool[0])
     return {'value': B / ms * 1e3, 'unit': 'patch-pairs/s', 'ms_per_step': ms, 'vs_resident': resident_ms / ms,
             'host_bytes_per_step': nbytes, 'pcie_GBps_sustained': nbytes / ms / 1e6,
-            'how': 'pinned host batches -> DeviceFeeder (copy stream, 2 device slots, event hand-off) -> TrainStep; '
+            'how': 'pinned host batches -> DeviceFeeder (copy stream, 3 device slots, event hand-off) -> TrainStep; '
                    'PCIe-inclusive, never the headline value'}
 
 
