@@ -14,7 +14,8 @@ large (default 4 slices of ~13 MB, the last one split once more so that only ~1 
 rather than many small NVSwitch-style ones.
 
 This module is pure torch.distributed logic and runs unchanged on CPU tensors with the gloo
-backend (tests/test_parallel_cpu.py, world_size 2).
+backend (tests/test_host_cpu.py::test_grad_bucketer_gloo_world2, world_size 2); tests/test_gpu_ddp.py runs the full step with
+two ranks on one GPU (gloo) and, where two devices are visible, over RCCL.
 """
 import torch
 import torch.distributed as dist
