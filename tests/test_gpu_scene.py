@@ -151,6 +151,35 @@ def test_predict_scene_full_size_properties():
     assert np.array_equal(inf.full_image_mask(out, hs, ws, lc, lr, h, w, p).astype(np.uint8), a.cpu().numpy())
 
 
+def test_predict_scene_at_the_full_baseline_size():
+    """BASELINE configs[4] at its full size -- 13 bands, 10 000 x 10 000, 128-pixel tiles = 6 241 tiles, 10.4 GB of float32 scene
+    planes resident in HBM -- through size-independent properties: the tile plan is the reference's (78 x 78 aligned tiles + 78 +
+    78 edge-anchored + the corner), the scan is reproducible bit for bit, a 2-way sharded scan merges to the single scan, and the
+    edge-anchored tiles cover the border (stitching an all-zero prediction over a poisoned mask leaves no pixel untouched)."""
+    c, h, w, p = 13, 10000, 10000, 128
+    g = torch.Generator(device='cuda').manual_seed(17)
+    d1 = torch.randn(c, h, w, device='cuda', generator=g)
+    d2 = d1 + 0.5 * torch.randn(c, h, w, device='cuda', generator=g)
+    model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().eval()
+    o, hs, ws, lc, lr = inf.tile_origins(h, w, p)
+    assert (hs, ws, lc, lr) == (78, 78, 78, 78) and len(o) == 6241
+    a = inf.predict_scene(model, d1, d2, patch_size=p, batch_size=64)
+    b = inf.predict_scene(model, d1, d2, patch_size=p, batch_size=64)
+    assert a.shape == (h, w) and a.dtype == torch.uint8 and torch.equal(a, b)
+    assert int(a.max()) <= 1
+    parts = [inf.predict_scene(model, d1, d2, patch_size=p, batch_size=64, shard=(r, 2), merge=False) for r in range(2)]
+    assert torch.equal(torch.maximum(parts[0], parts[1]), a)
+    del parts, b
+    full = torch.full((h, w), 255, dtype=torch.uint8, device='cuda')
+    from fabric_amd._lib import call, ptr, stream_ptr
+    origins = torch.from_numpy(o).cuda()
+    logits = torch.zeros(64, 2, p, p, device='cuda')
+    for i in range(0, len(o), 64):
+        oo = origins[i:i + 64]
+        call('bdn_argmax_stitch', ptr(logits), ptr(oo), ptr(full), oo.shape[0], 2, p, h, w, stream_ptr())
+    assert int(full.max()) == 0                                   # every pixel of the scene is owned by some tile
+
+
 def test_scene_errors():
     model = filler.fill_module(BiDateNet(3, 2, precision='fp32')).cuda()
     d = torch.zeros(3, 64, 64)
