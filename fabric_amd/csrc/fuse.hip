@@ -495,6 +495,22 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
     for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
         const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
         const bool pooled = dP != nullptr && yc < Ho && xc < Wo;   // floor-mode pooling leaves a trailing odd row/col unpooled
+        // every input of the cell is requested up front (z of both dates: 8 units, dF: 4, dP: 2) and z is kept in registers for
+        // both passes: the first version re-loaded z in pass 2 behind the wait of pass 1 -- two dependent round trips per cell
+        uint4 zq0[4], zq1[4], dfq[4], gq0 = make_uint4(0, 0, 0, 0), gq1 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            const bool in = y < H && x < W;
+            const size_t p0 = ((size_t)(b * H + (in ? y : 2 * yc)) * W + (in ? x : 2 * xc)), p1 = p0 + (size_t)B * H * W;
+            zq0[k] = *reinterpret_cast<const uint4*>(z + p0 * C + c);
+            zq1[k] = *reinterpret_cast<const uint4*>(z + p1 * C + c);
+            dfq[k] = *reinterpret_cast<const uint4*>(dF + p0 * ldF + c);
+        }
+        if (pooled) {
+            gq0 = *reinterpret_cast<const uint4*>(dP + ((size_t)(b * Ho + yc) * Wo + xc) * C + c);
+            gq1 = *reinterpret_cast<const uint4*>(dP + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c);
+        }
         // ---- pass 1: position of the FIRST maximum of each window (strict >, like ATen's max_pool2d)
         unsigned idx0 = 0, idx1 = 0;                               // 2 bits per channel
         if (pooled) {
@@ -503,10 +519,9 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
             for (int i = 0; i < EPU; i++) { m0[i] = -1.f; m1[i] = -1.f; }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);      // pooled windows are complete
-                float f0[EPU], f1[EPU];
-                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)(b * H + y) * W + x) * C + c), f0);
-                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + ((size_t)((B + b) * H + y) * W + x) * C + c), f1);
+                float f0[EPU], f1[EPU];                                      // pooled windows are complete
+                Unit<T>::unpack(zq0[k], f0);
+                Unit<T>::unpack(zq1[k], f1);
 #pragma unroll
                 for (int i = 0; i < EPU; i++) {
                     const float a0 = act1<T>(f0[i], sc0[i], sh0[i]), a1 = act1<T>(f1[i], sc1[i], sh1[i]);
@@ -518,10 +533,7 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
         float g0[EPU], g1[EPU];
 #pragma unroll
         for (int i = 0; i < EPU; i++) { g0[i] = 0.f; g1[i] = 0.f; }
-        if (pooled) {
-            Unit<T>::unpack(*reinterpret_cast<const uint4*>(dP + ((size_t)(b * Ho + yc) * Wo + xc) * C + c), g0);
-            Unit<T>::unpack(*reinterpret_cast<const uint4*>(dP + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c), g1);
-        }
+        if (pooled) { Unit<T>::unpack(gq0, g0); Unit<T>::unpack(gq1, g1); }
         // ---- pass 2: gradients (and statistics)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -529,9 +541,9 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
             if (y < H && x < W) {
                 float f0[EPU], f1[EPU], df[EPU], o0[EPU], o1[EPU];
                 const size_t p0 = ((size_t)(b * H + y) * W + x), p1 = ((size_t)((B + b) * H + y) * W + x);
-                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p0 * C + c), f0);
-                Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + p1 * C + c), f1);
-                Unit<T>::unpack(*reinterpret_cast<const uint4*>(dF + p0 * ldF + c), df);
+                Unit<T>::unpack(zq0[k], f0);
+                Unit<T>::unpack(zq1[k], f1);
+                Unit<T>::unpack(dfq[k], df);
 #pragma unroll
                 for (int i = 0; i < EPU; i++) {
                     const float a0 = act1<T>(f0[i], sc0[i], sh0[i]), a1 = act1<T>(f1[i], sc1[i], sh1[i]);
