@@ -51,8 +51,10 @@ __device__ __forceinline__ uint4 tr_pair(const unsigned char* p0, const unsigned
 
 // KSPLIT: for inputs with <= 32 channels the second half of the 64-wide ci tile is empty; the two waves
 // that would own it take every other 16-pixel k-step instead and write their own partial slice.
+// f32: nine 32x32 accumulators + 20 staging units of 16 bytes do not fit 256 registers (33-51 spilled in round 1), so the f32
+// instantiations are compiled for one block per CU
 template <typename T, int TH, int TW, int TI, bool KSPLIT>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void wgrad_kernel(WgradArgs a) {
     using CF = WgCfg<T, TH, TW, TI>;
     using TL = typename CF::TL;
     constexpr int STR = CF::STR, EPU = ET<T>::EPU, UPP = CF::CKB / 16;
