@@ -205,7 +205,9 @@ class BiDateEngine:
                                         # (bdn_conv3x3_act), so that layer's weight-gradient GEMM gets a plain operand (LDS-DMA kernel)
                                         # without any extra pass
         self.wgrad_kernel = 0           # A/B: per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
-        self.wgrad_blocks = 0           # A/B: per-call target grid of the weight-gradient GEMM (0 = default: one block per CU)
+        self.wgrad_blocks = 0           # A/B: per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
+        self.wgrad_blocks_tail = 0      # A/B: the same for the LAST GEMMs of backward (e1b, e2a): the chain has almost ended by then
+        self.wgrad_tail_layers = ('e1b',)
         self.wgrad_sched = 0            # how the weight-gradient GEMMs are placed beside the dz chain (both are MFMA-bound; two
                                         # MFMA kernels sharing the chip LOSE throughput, an MFMA kernel beside an HBM-bound one gains):
                                         #   0  released as soon as their dz exists (overlap whatever the chain runs next)
@@ -477,10 +479,11 @@ class BiDateEngine:
                      ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, 3, stp)
                 return
             wk_ = self.wgrad_kernel
+            blk_ = self.wgrad_blocks_tail if (self.wgrad_blocks_tail and L.name in self.wgrad_tail_layers) else self.wgrad_blocks
             if mode == IN_BNRELU and in0.data_ptr() in ws.act_valid:
                 in0, mode, in_bn = ws.act[in0.data_ptr()], IN_PLAIN, None      # written by this layer's forward (bdn_conv3x3_act)
             if mode == IN_BNRELU and self.wgrad_dma and \
-                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_, self.wgrad_blocks)) in (WG_DMA, WG_DMA2):
+                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_, blk_)) in (WG_DMA, WG_DMA2):
                 # the DMA kernel's operands never pass through registers: write a = relu(bn(z)) once (instead of deriving it in
                 # each of the Cout/64 column-tile blocks of the GEMM) and hand the GEMM a plain tensor
                 act = sc['act'][:in0.numel()]
@@ -490,7 +493,7 @@ class BiDateEngine:
                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
             name = None
             if self.prof is not None:
-                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_, self.wgrad_blocks))
+                v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_, blk_))
                 if v in (WG_DMA, WG_DMA2):
                     name = f'wgrad6_kernel<{3 if v == WG_DMA else 2}>'
                 elif v == WG_PIPE:
@@ -506,13 +509,13 @@ class BiDateEngine:
                     if self._prof_seen - 1 != self.prof_pick:
                         name = None
             if name is None:
-                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(3, wk_, self.wgrad_blocks), stp)
+                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(3, wk_, blk_), stp)
                 return
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(1, wk_, self.wgrad_blocks), stp)
+            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(1, wk_, blk_), stp)
             e1.record()
-            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(2, wk_, self.wgrad_blocks), stp)
+            call('bdn_conv3x3_wgrad_ex', *args, wg_flags(2, wk_, blk_), stp)
             self.prof.append((name, 2.0 * n * hk * wk * L.cout * 9 * (c0 + c1), e0, e1))
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
