@@ -88,7 +88,9 @@ struct ConvCfg {
     static constexpr int ROWS_ALLOC = ((NPU0 * 256 / UPP) + TL::PW - 1) / TL::PW;
     static constexpr int PATCH_ROWS = (BF && ROWS_ALLOC > TI * TL::PH) ? ROWS_ALLOC : TI * TL::PH;   // BF: branch-free staging
     static constexpr int PATCH_BYTES = PATCH_ROWS * ROWP;
-    static constexpr int PBUF = (2 * PATCH_BYTES <= 64 * 1024) ? 2 : 1;   // double-buffer when two blocks still fit a CU
+    // double-buffer when two blocks still fit a CU; the single-chunk kernels (BF == false) never fill a second buffer, and without
+    // it their 8x16 instantiation fits three blocks per CU instead of two
+    static constexpr int PBUF = (BF && 2 * PATCH_BYTES <= 64 * 1024) ? 2 : 1;
     static constexpr int OSTR = BN * OES + 16;
     static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
     static constexpr int MAIN_BYTES = PBUF * PATCH_BYTES;
