@@ -60,3 +60,32 @@ def test_epoch_and_validation_helpers():
     assert 0.0 <= v['cd_f1scores'] <= 1.0 and 0.0 <= v['cd_corrects'] <= 100.0
     sd = model.state_dict()
     assert int(sd['inc.conv.conv.1.num_batches_tracked']) == 2 * 2 * len(tr)   # eval passes leave the buffers alone
+
+
+@pytest.mark.parametrize('loss_function', ['tversky', 'dice'])
+def test_train_main_runs_an_epoch_and_writes_the_best_checkpoint(tmp_path, loss_function, capsys):
+    """python -m fabric_amd.train on synthetic cities: one epoch (fused step for tversky, the autograd path for the other
+    criteria), validation metrics in the reference's names, and train.py:207-227's artefacts -- the pickled module and the
+    metadata JSON -- which reload into a model that reproduces the validation logits."""
+    import json
+    from fabric_amd import train as T
+    T.main(['--synthetic', '--epochs', '1', '--batch_size', '8', '--patch_size', '64', '--stride', '128', '--num_workers', '0',
+            '--learning_rate', '0.02', '--loss_function', loss_function, '--log_dir', str(tmp_path)])
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line['epoch'] == 0 and {'train_cd_losses', 'validate_cd_f1scores', 'validate_cd_corrects'} <= set(line)
+    assert 0.0 <= line['validate_cd_f1scores'] <= 1.0
+    meta = json.load(open(tmp_path / 'metadata_epoch_0.json'))
+    assert meta['loss_function'] == loss_function and 'validation_metrics' in meta and meta['world_size'] == 1
+    model = torch.load(tmp_path / 'checkpoint_epoch_0.pt', weights_only=False)
+    assert isinstance(model, BiDateNet) and len(model.state_dict()) == 128
+    model = model.cuda().eval()
+    x = torch.randn(2, 13, 64, 64, device='cuda')
+    with torch.no_grad():
+        a = model(x, x.flip(0))
+    ref = BiDateNet(13, 2, precision=model.precision).cuda().eval()
+    ref.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        b = ref(x, x.flip(0))
+    assert torch.equal(a, b)
+    with pytest.raises(SystemExit):
+        T.main(['--synthetic', '--loss_function', 'bce'])
