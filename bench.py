@@ -200,7 +200,8 @@ def host_fed_leg(ts, dev, B, C, S, steps, warmup, x1, x2, lbl):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
-    fed(max(warmup, 4))                                    # slot allocation, first copies
+    fed(max(warmup, 80))                                   # slot allocation, first copies -- and the copy path's own warm-up: the first
+                                                           # ~80 host-fed steps of a process run 4 % slower than the steady state that follows
     res_a = _time_steps(ts, x1, x2, lbl, 2, max(steps // 2, 10)) * 1e3
     ms = fed(steps)
     res_b = _time_steps(ts, x1, x2, lbl, 2, max(steps // 2, 10)) * 1e3
