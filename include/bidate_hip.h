@@ -131,7 +131,7 @@ int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
  *              bracket the GEMM alone by issuing the phases apart);
  *   bits 8-11  kernel override (0 = the library's choice): BDN_WG_SIMPLE, BDN_WG_PIPE, BDN_WG_DMA, BDN_WG_DMA2 -- honoured where the
  *              shape class allows it, ignored otherwise (ask bdn_conv3x3_wgrad_variant what a call will run);
- *   bits 16-28 target number of blocks of the GEMM (0 = default 256, one per CU).
+ *   bits 16-28 target number of blocks of the GEMM (0 = default 128: half the CUs, the GEMM shares the chip with the dz chain).
  * With non-default flags `partial` must hold bdn_wgrad_workspace_bytes_ex(same arguments).  Results are deterministic
  * for fixed flags; different plans differ only in the summation order of the partial tiles. */
 #define BDN_WG_SIMPLE 1      /* one-chunk-at-a-time kernel (any dtype, first layer, 8x8 maps) */
