@@ -23,6 +23,7 @@ class _Slot:
         self.pin = None          # pinned staging tensors (only for pageable sources)
         self.ready = torch.cuda.Event()
         self.free = None         # recorded on the consumer's stream after it used the slot
+        self.issued = False
 
 
 class DeviceFeeder:
@@ -44,6 +45,9 @@ class DeviceFeeder:
             return batch
         if slot.pin is None or any(p.shape != t.shape or p.dtype != t.dtype for p, t in zip(slot.pin, batch)):
             slot.pin = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in batch]
+        elif slot.issued:
+            slot.ready.synchronize()      # the DMA that read this staging buffer `depth` batches ago must be over before the host
+                                          # overwrites it (the host runs far ahead of the copy stream, which waits for the consumer)
         jobs = []
         for p, t in zip(slot.pin, batch):
             t = t.contiguous()
@@ -61,14 +65,18 @@ class DeviceFeeder:
     def _issue(self, slot, batch):
         batch = [torch.as_tensor(t) for t in batch]
         src = self._pinned(slot, batch)
-        if slot.dev is None or any(d.shape != t.shape or d.dtype != t.dtype for d, t in zip(slot.dev, src)):
-            slot.dev = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in src]
         if slot.free is not None:
             self.copy_stream.wait_event(slot.free)       # the step that read this slot last is done with it
         with torch.cuda.stream(self.copy_stream):
+            if slot.dev is None or any(d.shape != t.shape or d.dtype != t.dtype for d, t in zip(slot.dev, src)):
+                # allocated UNDER the copy stream: a block handed out by the consumer stream's pool may still be in use by kernels
+                # that stream has queued (its temporaries are freed on the host long before they are dead on the device), and
+                # the copy stream would write into it unordered
+                slot.dev = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in src]
             for d, t in zip(slot.dev, src):
                 d.copy_(t, non_blocking=True)
             slot.ready.record(self.copy_stream)
+        slot.issued = True
 
     # ------------------------------------------------------------------ iteration
     def __call__(self, batches):
@@ -89,6 +97,8 @@ class DeviceFeeder:
                 nxt = None
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(slot.ready)
+            for t in slot.dev:
+                t.record_stream(cur)                     # allocated on the copy stream, read on the consumer's
             yield tuple(slot.dev)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))   # whatever the consumer enqueued on its stream reads the slot before this

@@ -83,7 +83,7 @@ print('ok', rank, err)
 def _run(tmp_path, precision, channels, delay, backend='gloo'):
     script = tmp_path / 'ddp_worker.py'
     script.write_text(_WORKER)
-    port = str(31000 + (os.getpid() * 7 + channels + 2 * int(delay) + (5 if precision == 'bf16' else 0)) % 2000)
+    port = str(31000 + (os.getpid() * 7 + channels + 2 * int(delay) + {'fp32': 0, 'bf16': 5, 'bf16x3': 11}[precision]) % 2000)
     procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', ROOT, port, precision, str(channels),
                                '1' if delay else '0', backend],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
@@ -105,6 +105,11 @@ def test_bf16_13band_two_ranks_fused_first_wgrad_path(tmp_path, delay):
 
 def test_fp32_two_ranks_delayed_side_stream(tmp_path):
     _run(tmp_path, 'fp32', 3, True)
+
+
+def test_bf16x3_two_ranks(tmp_path):
+    """The split-operand setting runs its weight gradients on the main stream: every bucket is released from there."""
+    _run(tmp_path, 'bf16x3', 13, False)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank')
