@@ -140,8 +140,9 @@ class Workspace:
         self.leased = False        # True while a live autograd graph still needs this workspace's z / bn tables for its backward
 
     def split_buf(self, which, numel):
-        """bf16x3: scratch for a split GEMM operand ([.., 2C] bf16 = hi | lo).  'a' activations, 'd' gradients, 'w' the wgrad's own
-        activation operand; grown on demand, reused by every layer (single-stream schedule, so in-order reuse is safe)."""
+        """bf16x3: scratch for a split GEMM operand ([.., 2C] bf16 = hi | lo).  'a' activations and 'd' gradients on the chain's stream;
+        'wd' / 'w' / 'p' the weight-gradient GEMM's own dz / activation operands and workspace on its stream.  Grown on demand,
+        reused by every layer: each buffer is only ever touched by ONE stream, so in-order reuse is safe."""
         t = self._split.get(which)
         if t is None or t.numel() < numel:
             t = torch.empty(numel, dtype=torch.bfloat16, device=self.x0.device)
@@ -181,6 +182,7 @@ class BiDateEngine:
         self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32                  # storage type: what the HBM-bound kernels see
         self.mdt = BDN_BF16X3 if precision == 'bf16x3' else self.dt             # what the GEMM kernels (conv3x3, wgrad, weight packing) see
         self.x3 = precision == 'bf16x3'
+        self.x3_side_stream = True      # A/B switch: bf16x3 weight gradients on the second stream too (own operand-split buffers)
         self.tdtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.esize = 2 if precision == 'bf16' else 4
         self.cp = _round_up(n_channels, 16)
@@ -448,7 +450,7 @@ class BiDateEngine:
         e = lambda *s: torch.empty(*s, dtype=td, device=dev)
         ready = on_ready or (lambda keys: None)
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if wgrad_stream and not self.x3 else None     # bf16x3 reuses one set of operand-split buffers: one stream
+        side = self._side_stream(dev) if wgrad_stream and not (self.x3 and not self.x3_side_stream) else None
 
         def bn_bwd(L, dA, ldA, n, ipg, fused_rows=0):
             """BatchNorm+ReLU backward of layer L.  fused_rows > 0: the kernel that produced dA already left the
@@ -469,7 +471,7 @@ class BiDateEngine:
             recorded on the stream it is launched on."""
             lib = _lib.load()
             if self.x3:
-                sd = ws.split_buf('d', n * hk * wk * 2 * L.cout)
+                sd = ws.split_buf('wd', n * hk * wk * 2 * L.cout)        # own buffers: this runs on the weight-gradient stream, in order
                 sw = ws.split_buf('w', n * hk * wk * 2 * (c0 + c1))
                 call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sd), n, hk, wk, stp)
                 call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg, ptr(sw), n, hk, wk, stp)
