@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
     const int half = lane >> 5, l31 = lane & 31;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = logical % a.n_ntiles, mtile = logical / a.n_ntiles;
+    const int ntile = logical % a.n_ntiles, mtile = logical / a.n_ntiles;   // block-uniform scalar divisions (shifts for power-of-two grids measured no faster)
     const int tx = mtile % a.tiles_x, ty = (mtile / a.tiles_x) % a.tiles_y, ib = mtile / (a.tiles_x * a.tiles_y);
     const int n0 = ib * TI, y0 = ty * TH, x0 = tx * TW, col0 = ntile * BN;
     const int Cin = D3 ? 3 * a.C0 : a.C0 + a.C1;
@@ -134,18 +134,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
     const int dslice = D3 ? n0 % a.Dz : 0;
     const unsigned dmask = D3 ? ((dslice > 0 ? 1u : 0u) | 2u | (dslice + 1 < a.Dz ? 4u : 0u)) : 7u;
     static_assert(!D3 || TI == 1, "a 3x3x3 tile belongs to one depth slice");
-
-    int a_off[MI];                                       // per-lane LDS offsets of the A rows (pixel slots)
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) a_off[mi] = CF::slot_off((wm * MI + mi) * 32 + l31) + half * 16;
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-        for (int nj = 0; nj < NJ; nj++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mi][nj][r] = 0.f;
 
     // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
     int p_pix[NPU];                                      // global pixel index of each unit (-1 = zero padding)
@@ -171,6 +159,7 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
         }
     }
     const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
+    const unsigned p_subb = (unsigned)p_sub * CF::ES;
     const bool write_act = ACT && a.act_out != nullptr && ntile == 0;
     // padding units load SOME valid pixel (zeroed at the store): pixel 0 of the tensor in 2-D; in 3x3x3 mode the sources are
     // shifted by a slice (pixel 0 of the lower one lies in front of the tensor), so the tile's own origin pixel
@@ -186,9 +175,13 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
             src_ = reinterpret_cast<const T*>(!dv_ || s_ == 1 ? a.in1 : (s_ == 0 ? a.in0 : a.in2));     \
         } else if ((c0_) < a.C0) { src_ = reinterpret_cast<const T*>(a.in0); Cs_ = a.ld0; cs_ = (c0_); } \
         else { src_ = reinterpret_cast<const T*>(a.in1); Cs_ = a.ld1; cs_ = (c0_) - a.C0; }             \
-        _Pragma("unroll") for (int i = 0; i < NPU; i++)       /* padding units read pixel 0 and are zeroed at the store */ \
-            if (BRANCHFREE || p_pix[i] >= 0)                                                            \
-                preg[i] = *reinterpret_cast<const uint4*>(src_ + (size_t)(p_pix[i] >= 0 ? p_pix[i] : p_fall) * Cs_ + cs_ + p_sub); \
+        /* one block-uniform base + a 32-bit byte offset per unit (the entry points keep every tensor below 4 GB): the loads take \
+           the scalar-base addressing form, no 64-bit vector arithmetic, no branches.  Padding units read SOME valid pixel and \
+           are zeroed at the store */                                                                   \
+        const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(src_ + cs_);                  \
+        const unsigned cb_ = (unsigned)Cs_ * CF::ES;                                                    \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
+            preg[i] = *reinterpret_cast<const uint4*>(sb_ + ((unsigned)(p_pix[i] >= 0 ? p_pix[i] : p_fall) * cb_ + p_subb)); \
     }
 #define STORE_PATCH(c0_, buf_)                                                                           \
     {                                                                                                   \
@@ -222,6 +215,22 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
             }                                                                                           \
         }                                                                                               \
     }
+
+    // the first patch is requested before anything else is computed: the rest of the prologue (LDS offsets, accumulator
+    // clear, filter addressing) runs in the shadow of its HBM latency
+    LOAD_PATCH(0)
+
+    int a_off[MI];                                       // per-lane LDS offsets of the A rows (pixel slots)
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) a_off[mi] = CF::slot_off((wm * MI + mi) * 32 + l31) + half * 16;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int nj = 0; nj < NJ; nj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mi][nj][r] = 0.f;
 
     // ---- filter fragments: per wave NJ x KG records of 1 KB (64 lanes x 16 B), streamed one tap ahead from
     // the fragment-ordered image.  Named scalars on purpose (register arrays that meet a scheduling fence were
@@ -304,7 +313,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
 #define STEP3(s_) STEP((s_), r0, r2) STEP((s_) + 1, r1, r0) STEP((s_) + 2, r2, r1)
 
     // prologue: first patch -> LDS buffer 0, steps 0 and 1 -> ring slots 0 and 1
-    LOAD_PATCH(0)
     LOAD_R(r0, 0, 0)
     LOAD_R(r1, 1, 0)
     STORE_PATCH(0, 0)
@@ -387,9 +395,10 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
     constexpr int UPR = BN * CF::OES / 16;                   // 16-byte units per output pixel row
     constexpr int OEPU = 16 / CF::OES;                       // output elements per 16-byte unit
     static_assert(256 % UPR == 0 && UPR <= 64, "a thread keeps one channel unit through the copy-out loop");
-    TO* outp = reinterpret_cast<TO*>(a.out);
+    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)col0 * CF::OES;        // block-uniform bases + 32-bit byte offsets
     const bool bs = a.bs_z != nullptr;                       // block-uniform
-    const TO* bsz = reinterpret_cast<const TO*>(a.bs_z);
+    const unsigned char* bsz = reinterpret_cast<const unsigned char*>(a.bs_z) + (size_t)col0 * CF::OES;
+    const unsigned orow = (unsigned)a.Cout * CF::OES;
     const int bsub = (tid % UPR) * OEPU;                     // this thread's channels inside the block's column tile
     float bs0[OEPU], bs1[OEPU], bsc[OEPU], bsh[OEPU];
 #pragma unroll
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
         const int n = n0 + ti, y = y0 + py, x = x0 + px;
         if (n < a.N && y < a.H && x < a.W) {
             uint4 v = *reinterpret_cast<const uint4*>(otile + slot * CF::OSTR + sub * 16);
-            const size_t o = ((size_t)(n * a.H + y) * a.W + x) * a.Cout + col0 + sub * OEPU;
+            const unsigned o = (unsigned)((n * a.H + y) * a.W + x) * orow + (unsigned)sub * 16u;
             *reinterpret_cast<uint4*>(outp + o) = v;
             if (bs) {                                        // the stored (rounded) gradient is what BatchNorm backward sees
                 float fg[OEPU], fz[OEPU];
@@ -566,6 +575,12 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
         if (C0 % 16) BDN_FAIL(BDN_E_SHAPE, "conv3x3(bf16x3): C0=%d must be a multiple of 16", C0);
         a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0;
     }
+    {   // the kernels address every tensor as one uniform base + a 32-bit byte offset
+        const size_t npix = (size_t)N * H * W, es = dtype == BDN_F32 ? 4 : 2, oes = dtype == BDN_BF16 ? 2 : 4;
+        const size_t widest = (size_t)(a.ld0 > a.ld1 ? a.ld0 : a.ld1);
+        if (npix * widest * es >= ((size_t)1 << 32) || npix * (size_t)Cout * oes >= ((size_t)1 << 32))
+            BDN_FAIL(BDN_E_SHAPE, "conv3x3: a tensor of N*H*W=%zu pixels reaches 4 GB; split the batch", npix);
+    }
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
     a.bs_z = bs_z; a.bs_bn = bs_bn; a.in2 = nullptr; a.Dz = 0;
@@ -676,6 +691,8 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     if (in_mode == BDN_IN_BNRELU && !in_bn) BDN_FAIL(BDN_E_ARG, "conv3d: BNRELU input needs in_bn");
     if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3d: bad dtype %d (bf16 / f32)", dtype);
     const size_t es = dtype == BDN_BF16 ? 2 : 4, slice = (size_t)H * W * C * es;
+    if ((size_t)N * D * slice >= ((size_t)1 << 32) || (size_t)N * D * H * W * Cout * es >= ((size_t)1 << 32))
+        BDN_FAIL(BDN_E_SHAPE, "conv3d: a tensor reaches 4 GB (32-bit byte offsets inside the kernel); split the batch");
     ConvArgs a;
     a.in1 = in; a.in0 = static_cast<const unsigned char*>(in) - slice; a.in2 = static_cast<const unsigned char*>(in) + slice;
     a.C0 = C; a.C1 = C; a.ld0 = C; a.ld1 = C; a.Dz = D;
