@@ -59,7 +59,8 @@ int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stre
  * w: packed [Cout][9][C0+C1]; bias: [Cout] f32 or NULL.
  * out: [N,H,W,Cout].  stats_partial: NULL or [bdn_conv3x3_num_mtiles][2][Cout] f32 receiving
  * per-tile sum / sum-of-squares of the (bias-included, f32) outputs for the BatchNorm that follows.
- * The same entry point computes the data gradient when given wd and dz. */
+ * The same entry point computes the data gradient when given wd and dz.
+ * Every tensor must stay below 4 GB (the kernels address with one base + a 32-bit byte offset): BDN_E_SHAPE otherwise. */
 int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 int in_mode, const float* in_bn, int imgs_per_group,
                 const void* w, const float* bias, void* out, float* stats_partial,

@@ -41,6 +41,8 @@ def test_argument_validation_needs_no_gpu():
         _lib.call('bdn_conv3x3', 1, None, 64, None, 0, 0, None, 1, None, None, None, None, 1, 8, 8, 64, None)
     with pytest.raises(RuntimeError, match='multiple of 64'):
         _lib.call('bdn_conv3x3', 1, 1, 64, None, 0, 0, None, 1, 1, None, 1, None, 1, 8, 8, 65, None)
+    with pytest.raises(RuntimeError, match='4 GB'):       # 32-bit byte offsets inside the kernel: 4096 x 128 x 128 x 64 bf16 = 8 GB
+        _lib.call('bdn_conv3x3', 1, 1, 64, None, 0, 0, None, 1, 1, None, 1, None, 4096, 128, 128, 64, None)
     # round-2 entry points: plans are pure functions of their arguments, errors come before anything touches a device
     from fabric_amd._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_PIPE, WG_SIMPLE, wg_flags
     var = lib.bdn_conv3x3_wgrad_variant
