@@ -349,6 +349,47 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
     float* red = reinterpret_cast<float*>(smem + CF::BM * CF::OSTR);
     const bool do_stats = a.stats_partial != nullptr && a.bs_z == nullptr;
     const bool full_tile = (n0 + TI <= a.N) && (y0 + TH <= a.H) && (x0 + TW <= a.W);   // block-uniform
+    constexpr int UPR = BN * CF::OES / 16;                   // 16-byte units per output pixel row
+    constexpr int OEPU = 16 / CF::OES;                       // output elements per 16-byte unit
+    constexpr int NIT = CF::BM * UPR / 256;                  // copy-out units per thread
+    static_assert(256 % UPR == 0 && UPR <= 64 && (CF::BM * UPR) % 256 == 0, "a thread keeps one channel unit through the copy-out loop");
+    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)col0 * CF::OES;        // block-uniform bases + 32-bit byte offsets
+    const bool bs = !D3 && a.bs_z != nullptr;                // block-uniform
+    const unsigned char* bsz = reinterpret_cast<const unsigned char*>(a.bs_z) + (size_t)col0 * CF::OES;
+    // PRE: the copy-out offsets and (data-gradient launches with BatchNorm-backward statistics) the z units are produced
+    // BEFORE the accumulator pass; only where that costs at most 40 registers (16-bit outputs)
+    constexpr bool PRE = NIT <= 8 && !D3;
+    constexpr int NPRE = PRE ? NIT : 1;
+    const unsigned orow = (unsigned)a.Cout * CF::OES;
+    const int bsub = (tid % UPR) * OEPU;                     // this thread's channels inside the block's column tile
+    float bs0[OEPU], bs1[OEPU], bsc[OEPU], bsh[OEPU];
+#pragma unroll
+    for (int i = 0; i < OEPU; i++) { bs0[i] = 0.f; bs1[i] = 0.f; bsc[i] = 0.f; bsh[i] = 0.f; }
+#define OUT_OFS(i_, dst_)                                   /* byte offset of copy-out unit i_ in the output tensor, ~0 = outside the image */ \
+    {                                                                                                   \
+        const int u_ = tid + (i_) * 256, slot_ = u_ / UPR, sub_ = u_ % UPR;                             \
+        int ti_, py_, px_; TL::slot_to_nyx(slot_, ti_, py_, px_);                                       \
+        const int n_ = n0 + ti_, y_ = y0 + py_, x_ = x0 + px_;                                          \
+        dst_ = (n_ < a.N && y_ < a.H && x_ < a.W) ? (unsigned)((n_ * a.H + y_) * a.W + x_) * orow + (unsigned)sub_ * 16u : 0xffffffffu; \
+    }
+    unsigned oofs[NPRE];
+    uint4 zq[NPRE];
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) OUT_OFS(i, oofs[i])
+    }
+    if (bs) {
+        // the z units are requested HERE, a whole accumulator pass ahead of their use: inside the copy-out loop every one of them
+        // was a dependent HBM round trip behind the store before it (eight per block)
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < NPRE; i++) zq[i] = *reinterpret_cast<const uint4*>(bsz + (oofs[i] != 0xffffffffu ? oofs[i] : 0u));
+        }
+        const float* ps = bn_row(a.bs_bn, grp, 2, a.Cout) + col0 + bsub;
+        const float* ph = bn_row(a.bs_bn, grp, 3, a.Cout) + col0 + bsub;
+#pragma unroll
+        for (int i = 0; i < OEPU; i++) { bsc[i] = ps[i]; bsh[i] = ph[i]; }
+    }
     // Three block-uniform variants of the accumulator -> LDS pass, so the common cases carry no dead work:
     //   plain (data gradient: no bias, no statistics), full tile with statistics, ragged tile with statistics.
     // LDS addresses are one per-lane base + compile-time offsets (folded into the ds_write immediates).
@@ -392,43 +433,35 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
         a.stats_partial[((size_t)mtile * 2 + 0) * a.Cout + col0 + tid] = s;
         a.stats_partial[((size_t)mtile * 2 + 1) * a.Cout + col0 + tid] = q;
     }
-    constexpr int UPR = BN * CF::OES / 16;                   // 16-byte units per output pixel row
-    constexpr int OEPU = 16 / CF::OES;                       // output elements per 16-byte unit
-    static_assert(256 % UPR == 0 && UPR <= 64, "a thread keeps one channel unit through the copy-out loop");
-    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)col0 * CF::OES;        // block-uniform bases + 32-bit byte offsets
-    const bool bs = a.bs_z != nullptr;                       // block-uniform
-    const unsigned char* bsz = reinterpret_cast<const unsigned char*>(a.bs_z) + (size_t)col0 * CF::OES;
-    const unsigned orow = (unsigned)a.Cout * CF::OES;
-    const int bsub = (tid % UPR) * OEPU;                     // this thread's channels inside the block's column tile
-    float bs0[OEPU], bs1[OEPU], bsc[OEPU], bsh[OEPU];
-#pragma unroll
-    for (int i = 0; i < OEPU; i++) { bs0[i] = 0.f; bs1[i] = 0.f; bsc[i] = 0.f; bsh[i] = 0.f; }
-    if (bs) {
-        const float* ps = bn_row(a.bs_bn, grp, 2, a.Cout) + col0 + bsub;
-        const float* ph = bn_row(a.bs_bn, grp, 3, a.Cout) + col0 + bsub;
-#pragma unroll
-        for (int i = 0; i < OEPU; i++) { bsc[i] = ps[i]; bsh[i] = ph[i]; }
+    // copy-out: the tile leaves LDS in 16-byte NHWC units; the offsets were computed (and, for data-gradient launches with the
+    // BatchNorm-backward statistics, the z units requested) before the accumulator pass
+#define COPY_UNIT(i_, o_, zexpr_)                                                                        \
+    if ((o_) != 0xffffffffu) {                                                                          \
+        const int u_ = tid + (i_) * 256;                                                                \
+        uint4 v = *reinterpret_cast<const uint4*>(otile + (u_ / UPR) * CF::OSTR + (u_ % UPR) * 16);     \
+        *reinterpret_cast<uint4*>(outp + (o_)) = v;                                                     \
+        if (bs) {                                            /* the stored (rounded) gradient is what BatchNorm backward sees */ \
+            float fg[OEPU], fz[OEPU];                                                                   \
+            Unit<TO>::unpack(v, fg);                                                                    \
+            Unit<TO>::unpack(zexpr_, fz);                                                               \
+            _Pragma("unroll") for (int e = 0; e < OEPU; e++) {                                           \
+                const float g = fmaf(fz[e], bsc[e], bsh[e]) > 0.f ? fg[e] : 0.f;                        \
+                bs0[e] += g; bs1[e] = fmaf(g, fz[e], bs1[e]);                                           \
+            }                                                                                           \
+        }                                                                                               \
     }
-    for (int u = tid; u < CF::BM * UPR; u += 256) {
-        const int slot = u / UPR, sub = u % UPR;
-        int ti, py, px; TL::slot_to_nyx(slot, ti, py, px);
-        const int n = n0 + ti, y = y0 + py, x = x0 + px;
-        if (n < a.N && y < a.H && x < a.W) {
-            uint4 v = *reinterpret_cast<const uint4*>(otile + slot * CF::OSTR + sub * 16);
-            const unsigned o = (unsigned)((n * a.H + y) * a.W + x) * orow + (unsigned)sub * 16u;
-            *reinterpret_cast<uint4*>(outp + o) = v;
-            if (bs) {                                        // the stored (rounded) gradient is what BatchNorm backward sees
-                float fg[OEPU], fz[OEPU];
-                Unit<TO>::unpack(v, fg);
-                Unit<TO>::unpack(*reinterpret_cast<const uint4*>(bsz + o), fz);
+    if constexpr (PRE) {
 #pragma unroll
-                for (int i = 0; i < OEPU; i++) {
-                    const float g = fmaf(fz[i], bsc[i], bsh[i]) > 0.f ? fg[i] : 0.f;
-                    bs0[i] += g; bs1[i] = fmaf(g, fz[i], bs1[i]);
-                }
-            }
+        for (int i = 0; i < NPRE; i++) COPY_UNIT(i, oofs[i], zq[i])
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < NIT; i++) {
+            unsigned o; OUT_OFS(i, o)
+            COPY_UNIT(i, o, *reinterpret_cast<const uint4*>(bsz + o))
         }
     }
+#undef COPY_UNIT
+#undef OUT_OFS
     if (bs) {
         // lanes tid, tid+UPR, ... of a wave hold the same channels: butterfly over those lane bits, then the four
         // waves meet in LDS (fixed order -> deterministic)

@@ -47,12 +47,20 @@ if what in ('conv', 'all'):
         nt = lib.bdn_conv3x3_num_mtiles(n, h, w, co, ipg)
         stats = torch.empty(nt * 2 * co, device='cuda')
         fwd = 'fwd' in tag
-        fn = lambda: _lib.call('bdn_conv3x3', dt, a0.data_ptr(), c0, a1.data_ptr() if c1 else None, c1, mode, bn.data_ptr(), ipg,
+        if os.environ.get('BS') and tag[2:] == 'b dgrad':          # as in the training step: + BatchNorm-backward sums of the 'a' layer in the epilogue
+            zprev = torch.randn(n, h, w, co, device='cuda').to(td)
+            bnp = torch.rand(2, 4, co, device='cuda') + 0.5
+            part = torch.empty(nt * 2 * co, device='cuda')
+            fn = lambda: _lib.call('bdn_conv3x3_dgrad_bs', dt, a0.data_ptr(), c0, wt.data_ptr(), out.data_ptr(), zprev.data_ptr(), bnp.data_ptr(), ipg,
+                                   part.data_ptr(), n, h, w, co, st)
+            tag = tag + '+bs'
+        else:
+          fn = lambda: _lib.call('bdn_conv3x3', dt, a0.data_ptr(), c0, a1.data_ptr() if c1 else None, c1, mode, bn.data_ptr(), ipg,
                                wt.data_ptr(), bias.data_ptr() if fwd else None, out.data_ptr(), stats.data_ptr() if fwd else None, n, h, w, co, st)
         t = timeit(fn)
         fl = 2.0 * n * h * w * co * 9 * (c0 + c1)
         tot_t += t; tot_f += fl
-        print(f'{tag:10s} N={n:3d} {h:3d}x{w:3d} Cin={c0 + c1:4d} Cout={co:4d} mode={mode}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF/s')
+        print(f'{tag:13s} N={n:3d} {h:3d}x{w:3d} Cin={c0 + c1:4d} Cout={co:4d} mode={mode}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF/s')
     print(f'conv total {tot_t * 1e3:.3f} ms  {tot_f / tot_t / 1e12:.1f} TF/s')
 wt_t = wt_f = 0
 if what in ('wgrad', 'all'):
