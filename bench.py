@@ -226,7 +226,7 @@ def parity_leg(dev, B, C, S):
     torch.manual_seed(4321)
     sd = {k: v.clone() for k, v in BiDateNet(C, 2).state_dict().items()}
     out, logits = {}, {}
-    for prec, warm, n in (('fp32', 1, 3), ('bf16x3', 2, 6), ('bf16', 2, 6)):
+    for prec, warm, n in (('fp32', 2, 4), ('bf16x3', 5, 15), ('bf16', 2, 6)):
         m = BiDateNet(C, 2, precision=prec)
         m.load_state_dict(sd)
         m = m.to(dev).train()
