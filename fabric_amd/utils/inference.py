@@ -122,7 +122,11 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
     utils/dataloaders.py:86-101); moved to the model's device if they are not there yet.
     Returns a uint8 [H,W] device tensor equal to ``_get_bands(argmax(model(tiles)))`` of the reference loop.
     shard=(rank, world): process only this rank's contiguous slice of the tile list; merge=True then combines
-    the per-rank masks with one all-reduce(MAX) over the default process group (unwritten pixels are 0)."""
+    the per-rank masks with one all-reduce(MAX) over the default process group (unwritten pixels are 0).
+    batch_size: tiles per forward batch (256 is the fastest on MI355X, bench.py scene leg); every activation tensor must stay below
+    4 GB (2 * batch_size * patch_size^2 * 64 channels * 2 bytes), i.e. at most 1023 tiles of 128 x 128."""
+    if 2 * batch_size * patch_size * patch_size * 64 * 2 >= 1 << 32:
+        raise ValueError(f'batch_size={batch_size} tiles of {patch_size} px make a 4 GB activation tensor; use a smaller batch')
     P = _eval_params(model)
     eng = model.engine()
     dev = next(model.parameters()).device
