@@ -395,6 +395,13 @@ def main():
                                          'per_kernel_ms': {k: round(v[2] * 1e3, 3) for k, v in sorted(conv_all.items(), key=lambda kv: -kv[1][2])},
                                          'seconds_per_step': conv_total,
                                          'achieved': sum(v[1] for v in conv_all.values()) / conv_total / 1e12}}
+        if name.startswith('wgrad') and name != 'wgrad_first_kernel':
+            # the weight-gradient GEMMs run on the second stream beside the dz chain, on a grid of HALF the CUs by design
+            # (fabric_amd/csrc/wgrad.hip wgrad_plan; engine.wgrad_blocks overrides): `frac` above is against the FULL-chip peak
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            blocks = eng.wgrad_blocks or 128
+            roofline['grid'] = {'blocks': blocks, 'cus': cus, 'concurrent_with': 'the dz chain (data-gradient convs, BatchNorm / unpool / upsample backward) on the other stream',
+                                'frac_of_occupied_cus': achieved / peak * cus / min(blocks, cus)}
     if rank == 0:
         pairs = args.steps * B * world
         value = pairs / elapsed
