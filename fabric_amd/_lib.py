@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('BIDATE_LIB') or os.path.join(_HERE, 'csrc', 'libbidat
 
 BDN_F32, BDN_BF16, BDN_BF16X3 = 0, 1, 2
 IN_PLAIN, IN_BNRELU = 0, 1
-WG_SIMPLE, WG_PIPE, WG_DMA, WG_DMA2 = 1, 2, 3, 4
+WG_SIMPLE, WG_PIPE, WG_DMA, WG_DMA2, WG_ROLE = 1, 2, 3, 4, 5
 
 
 def wg_flags(phases=3, kernel=0, blocks=0):

@@ -686,6 +686,281 @@ static int launch_wgrad6(const WgradArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// wgrad7 (BDN_WG_ROLE): wgrad6's tile, LDS image, split plan and MFMA order (results bit-identical to wgrad2 / wgrad6) with the
+// block split by ROLE -- made for the half-chip grid, where a weight-gradient block owns its CU anyway:
+//   waves 0-3  CONSUMERS, one per SIMD: 76 transposing fragment reads + 72 MFMAs per chunk and nothing else;
+//   waves 4-7  PRODUCERS, one per SIMD beside a consumer: everything that stalls a lone MFMA wave in wgrad2 -- the global
+//              loads of the halo patch (two chunks ahead, through two register sets), BatchNorm+ReLU of the producing layer,
+//              zero masks, ds_write_b128 -- and the LDS-DMA of the dz tile (plain, two chunks ahead: three LDS buffers).
+// USE_BN = false: the patch goes by LDS-DMA too and a producer's chunk is ten DMA instructions.
+// Every vector-memory instruction of the producer path is inline asm and is waited for by hand: hipcc's wait-count pass cannot
+// see the LDS-DMAs, so any wait it derived for a visible load would be off by the DMAs in flight (an over-wait of a whole HBM
+// latency per chunk).  Issue order per chunk q: DMA dz(q+2), loads patch(q+3), `s_waitcnt vmcnt(10)` (= patch(q+2) and
+// everything older, i.e. dz(q+1) too, has landed), BatchNorm + stores of patch(q+2), `lgkmcnt(0)`, barrier.
+__device__ __forceinline__ u32x4_t gload16_asm(const void* sbase, unsigned voff) {
+    u32x4_t r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+// scalar-FMA BatchNorm+ReLU of one 16-byte bf16 unit (packed f32 math beside another wave's MFMAs costs the matrix pipe)
+__device__ __forceinline__ uint32_t bnrelu_pair_s(uint32_t u, float s0, float s1, float t0, float t1) {
+    float y0 = __builtin_fmaf(__uint_as_float(u << 16), s0, t0);
+    float y1 = __builtin_fmaf(__uint_as_float(u & 0xffff0000u), s1, t1);
+    asm("" : "+v"(y0)); asm("" : "+v"(y1));                    // keep the SLP vectoriser from re-packing into v_pk_fma_f32
+    const f32x2_t y = {y0, y1};
+    const bf16x2_t r = __builtin_convertvector(y, bf16x2_t);
+    const s16x2_t zero = {0, 0};
+    const s16x2_t q = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, r), zero);
+    return __builtin_bit_cast(uint32_t, q);
+}
+
+template <bool USE_BN>
+__global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
+    constexpr int PW = Wg6::PW, STR = Wg6::STR, BUF = Wg6::BUF, PATCH_BYTES = Wg6::PATCH_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.n_cot * a.n_cit;
+    const int tile = logical % ntile, split = logical / ntile;
+    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
+    const int Cin = a.C0 + a.C1;
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    if (q_begin >= q_end) return;                              // (never: the plan leaves no empty split) -- uniform for the block
+
+    if (wave >= 4) {
+        // ================================================= producer
+        const int pw = wave - 4;
+        const unsigned char* src; int Csrc, cs;
+        if (ci0 < a.C0) { src = reinterpret_cast<const unsigned char*>(a.in0); Csrc = a.C0; cs = ci0; }
+        else { src = reinterpret_cast<const unsigned char*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
+        const unsigned char* dzp = reinterpret_cast<const unsigned char*>(a.dz);
+        // ownership: piece i = LDS pixels 8 pw + 32 i .. +7; lane = (pixel u_pix of the piece, 16-byte slot sub)
+        const int u_pix = pw * 8 + (lane >> 3), sub = lane & 7;
+        const int swz = ((u_pix >> 1) & 1) << 2;                // pieces keep bit 1 of the pixel index
+        const int unit = sub ^ swz;                             // DMA: lane-linear LDS slot `sub` holds source channel unit `unit`
+        const unsigned wbase = u_pix * STR + unit * 16;         // register path: the lane loads channel unit `sub` and stores it at slot sub ^ swz
+        int pyx[6];
+        unsigned poff[6], poff_dma[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
+            pyx[i] = pix < Wg6::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
+            poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub * 8) * 2);
+            poff_dma[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + unit * 8) * 2);
+        }
+        const unsigned poff_c = (unsigned)(((a.W + 1) * Csrc + cs + sub * 8) * 2);    // the tile's origin pixel: always inside
+        const int dpx = u_pix & 15, dpy0 = u_pix >> 4;             // dz pieces: tile pixel (dpy0 + 2 i, dpx)
+        const unsigned drow2 = (unsigned)(2 * a.W * a.Cout * 2);
+        const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + unit * 8) * 2);
+        const unsigned lds_piece0 = (unsigned)(pw * 8 * STR);
+        const unsigned smem_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+        u32x4_t pA[6], pB[6];
+        unsigned mA = 0, mB = 0;
+        int gA = 0, gB = 0, cur_grp = -1;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
+        // cursor: the next chunk in sequence and its tile coordinates; c_* = the chunk it last evaluated
+        int lq = q_begin;
+        int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
+        int lg = ln / a.imgs_per_group;
+        bool c_live = false; int c_y0 = 0, c_x0 = 0, c_grp = 0; long c_pix = 0;
+#define W7_CUR()                                                                                         \
+        {                                                                                               \
+            c_live = lq < q_end;                                                                        \
+            c_y0 = lty * 8; c_x0 = ltx * 16;                                                            \
+            if (c_live) { c_pix = (long)(ln * a.H + c_y0) * a.W + c_x0; c_grp = lg; }                   \
+            if (c_live) {                                                                               \
+                lq++;                                                                                   \
+                if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
+            }                                                                                           \
+        }
+        // dz tile of the evaluated chunk -> buffer at byte offset wb_ (4 LDS-DMA pieces per wave)
+#define W7_DMA_D(wb_)                                                                                    \
+        {                                                                                               \
+            const u32x4_t rs_ = raw_rsrc(dzp + c_pix * a.Cout * 2, Wg6::NUM_RECORDS);                   \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                              \
+                const bool ok_ = c_live && (c_y0 + dpy0 + 2 * i) < a.H && (c_x0 + dpx) < a.W;           \
+                lds_dma16(rs_, smem_base + (wb_) + PATCH_BYTES + lds_piece0 + i * 32 * STR, ok_ ? doff0 + (unsigned)i * drow2 : Wg6::OOB); \
+            }                                                                                           \
+        }
+        // plain halo patch of the evaluated chunk -> buffer wb_ (6 LDS-DMA pieces per wave)
+#define W7_DMA_P(wb_)                                                                                    \
+        {                                                                                               \
+            const u32x4_t rs_ = raw_rsrc(src + (c_pix - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS);         \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
+                const int y_ = c_y0 + (pyx[i] >> 16), x_ = c_x0 + (short)(pyx[i] & 0xffff);             \
+                const bool ok_ = c_live && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W; \
+                lds_dma16(rs_, smem_base + (wb_) + lds_piece0 + i * 32 * STR, ok_ ? poff_dma[i] : Wg6::OOB); \
+            }                                                                                           \
+        }
+        // halo patch of the evaluated chunk -> register set (P, M, G): six global loads per lane
+#define W7_LOAD_P(P, M, G)                                                                               \
+        {                                                                                               \
+            const unsigned char* sp_ = src + (c_pix - a.W - 1) * Csrc * 2;                              \
+            if (c_live) G = c_grp;                                                                      \
+            unsigned m_ = 0;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
+                const int y_ = c_y0 + (pyx[i] >> 16), x_ = c_x0 + (short)(pyx[i] & 0xffff);             \
+                const bool ok_ = c_live && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W; \
+                P[i] = gload16_asm(sp_, ok_ ? poff[i] : poff_c);                                        \
+                m_ |= (ok_ ? 1u : 0u) << i;                                                             \
+            }                                                                                           \
+            M = m_;                                                                                     \
+        }
+        // wait until at most n_ vector-memory operations of this wave are in flight; the set's registers are operands so that
+        // no use of them is scheduled above the wait
+#define W7_WAIT_P(n_, P) asm volatile("s_waitcnt vmcnt(" #n_ ")" : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]) :: "memory");
+#define W7_GROUP(g_)                                                                                     \
+        if ((g_) != cur_grp) {                                                                          \
+            cur_grp = (g_);                                                                             \
+            const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub * 8;                        \
+            const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub * 8;                        \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }            \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7]), \
+                         "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(sh[4]), "+v"(sh[5]), "+v"(sh[6]), "+v"(sh[7]) :: "memory"); \
+        }
+        // BatchNorm+ReLU, zero mask and LDS store of the six units of a landed register set
+#define W7_STAGE(P, M, G, wb_)                                                                           \
+        {                                                                                               \
+            W7_GROUP(G)                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
+                const u32x4_t r_ = P[i];                                                                \
+                const bool ok_ = ((M) >> i) & 1u;                                                       \
+                const unsigned b0_ = bnrelu_pair_s(r_.x, sc[0], sc[1], sh[0], sh[1]), b1_ = bnrelu_pair_s(r_.y, sc[2], sc[3], sh[2], sh[3]); \
+                const unsigned b2_ = bnrelu_pair_s(r_.z, sc[4], sc[5], sh[4], sh[5]), b3_ = bnrelu_pair_s(r_.w, sc[6], sc[7], sh[6], sh[7]); \
+                u32x4_t v_;                                                                             \
+                v_.x = ok_ ? b0_ : 0u; v_.y = ok_ ? b1_ : 0u; v_.z = ok_ ? b2_ : 0u; v_.w = ok_ ? b3_ : 0u; \
+                *reinterpret_cast<u32x4_t*>(smem + (wb_) + wbase + i * 32 * STR) = v_;                  \
+            }                                                                                           \
+        }
+#define W7_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
+        if constexpr (USE_BN) {
+            // prologue: chunks q_begin / q_begin + 1 into buffers 0 / 1, the patch of chunk q_begin + 2 into set A
+            W7_CUR() W7_DMA_D(0) W7_LOAD_P(pA, mA, gA)
+            W7_CUR() W7_DMA_D(BUF) W7_LOAD_P(pB, mB, gB)
+            W7_WAIT_P(10, pA)
+            W7_STAGE(pA, mA, gA, 0)
+            W7_CUR() W7_LOAD_P(pA, mA, gA)
+            W7_WAIT_P(6, pB)
+            W7_STAGE(pB, mB, gB, BUF)
+            unsigned nxt = 2 * BUF;                                // buffer filled for chunk q + 2
+            for (int q = q_begin; q < q_end; q += 2) {
+                W7_BARRIER()
+                W7_DMA_D(nxt)                                      // dz(q+2): the chunk set A holds
+                W7_CUR() W7_LOAD_P(pB, mB, gB)                     // patch(q+3)
+                W7_WAIT_P(10, pA)
+                W7_STAGE(pA, mA, gA, nxt)
+                nxt = nxt == 2 * BUF ? 0 : nxt + BUF;
+                if (q + 1 >= q_end) break;
+                W7_BARRIER()
+                W7_DMA_D(nxt)
+                W7_CUR() W7_LOAD_P(pA, mA, gA)
+                W7_WAIT_P(10, pB)
+                W7_STAGE(pB, mB, gB, nxt)
+                nxt = nxt == 2 * BUF ? 0 : nxt + BUF;
+            }
+        } else {
+            W7_CUR() W7_DMA_P(0) W7_DMA_D(0)
+            W7_CUR() W7_DMA_P(BUF) W7_DMA_D(BUF)
+            unsigned nxt = 2 * BUF;
+            for (int q = q_begin; q < q_end; q++) {
+                // chunk q has landed when at most chunk q+1's ten pieces are still in flight
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                W7_CUR() W7_DMA_P(nxt) W7_DMA_D(nxt)
+                nxt = nxt == 2 * BUF ? 0 : nxt + BUF;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // trailing (all-zero) fetches: nothing may land after exit
+#undef W7_CUR
+#undef W7_DMA_D
+#undef W7_DMA_P
+#undef W7_LOAD_P
+#undef W7_WAIT_P
+#undef W7_GROUP
+#undef W7_STAGE
+#undef W7_BARRIER
+        return;
+    }
+
+    // ===================================================== consumer: wgrad2's row walk, fragment reads and MFMAs only
+    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int kpix = (lane & 15) >> 2;
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;
+    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
+    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
+    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
+#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
+    uint4 af[4], bq[2][3];
+#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
+#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
+#define WG_ROW(pr_)                                                                                      \
+    {                                                                                                   \
+        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
+        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) } \
+        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
+        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) } \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+    unsigned cur = 0;
+    for (int q = q_begin; q < q_end; q++) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char* rb = smem + cur;
+        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)
+        WG_ROW(0) WG_ROW(1) WG_ROW(2) WG_ROW(3) WG_ROW(4) WG_ROW(5) WG_ROW(6) WG_ROW(7) WG_ROW(8) WG_ROW(9)
+        cur = cur == 2 * BUF ? 0 : cur + BUF;
+    }
+#undef TRP
+#undef LDA
+#undef LDB
+#undef B_BASE
+#undef WG_MMA
+#undef WG_ROW
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
+        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;                 // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
+        }
+    }
+}
+
+template <bool USE_BN>
+static int launch_wgrad7(const WgradArgs& a, hipStream_t st) {
+    auto kern = wgrad7_kernel<USE_BN>;
+    BDN_SET_SMEM_ONCE(kern, 3 * Wg6::BUF, "wgrad7");
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(512), 3 * Wg6::BUF, st, a);
+    BDN_CHECK_LAUNCH("wgrad7");
+    return BDN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // wgrad_first: the FIRST layer's weight gradient with its BatchNorm+ReLU backward fused in.  The first conv has no data
 // gradient, so its dz (the largest tensor of the step, 2B x 128 x 128 x 64) has exactly one reader: this GEMM.  Writing it
 // with bn_bwd_apply and reading it back is a 0.8 GB round trip at the very end of the step, where nothing of the dz chain
@@ -942,10 +1217,12 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
     // LDS-DMA kernel: plain inputs only (no BatchNorm+ReLU on load), and every image row / channel run must be addressable
     // with 32-bit byte offsets from a chunk's halo origin (always true below 2^31 elements)
     const bool dma_ok = pipe_ok && in_mode == BDN_IN_PLAIN;
-    p.variant = pipe_ok ? (dma_ok ? BDN_WG_DMA : BDN_WG_PIPE) : BDN_WG_SIMPLE;
+    p.variant = pipe_ok ? BDN_WG_ROLE : BDN_WG_SIMPLE;      // role-split kernel: +10 % over the LDS-DMA kernel on plain operands, 1.5x wgrad2 with BatchNorm on load
+    if (want == BDN_WG_DMA && dma_ok) p.variant = BDN_WG_DMA;
     if (want == BDN_WG_SIMPLE) p.variant = BDN_WG_SIMPLE;
     if (want == BDN_WG_PIPE && pipe_ok) p.variant = BDN_WG_PIPE;
     if (want == BDN_WG_DMA2 && dma_ok) p.variant = BDN_WG_DMA2;
+    if (want == BDN_WG_ROLE && pipe_ok) p.variant = BDN_WG_ROLE;
     // the simple kernel (first layer / 8x8 maps / f32) has no software pipeline: it hides latency with a second block per CU
     int blocks = (flags >> 16) & 0x1fff;
     if (blocks == 0) blocks = 128;                          // HALF the CUs: the GEMM runs beside the dz chain on a second stream, and two MFMA kernels
@@ -1040,6 +1317,7 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     } else if (dtype == BDN_BF16) {
         if (p.variant == BDN_WG_DMA) rc = launch_wgrad6<3>(a, st);
         else if (p.variant == BDN_WG_DMA2) rc = launch_wgrad6<2>(a, st);
+        else if (p.variant == BDN_WG_ROLE) rc = a.in_bn ? launch_wgrad7<true>(a, st) : launch_wgrad7<false>(a, st);
         else if (p.variant == BDN_WG_PIPE) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
         else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_DMA2, WG_PIPE, call, ptr, wg_flags
+from ._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_DMA2, WG_PIPE, WG_ROLE, call, ptr, wg_flags
 
 ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
@@ -496,7 +496,9 @@ class BiDateEngine:
             name = None
             if self.prof is not None:
                 v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_, blk_))
-                if v in (WG_DMA, WG_DMA2):
+                if v == WG_ROLE:
+                    name = f'wgrad7_kernel<{"true" if mode == IN_BNRELU else "false"}>'
+                elif v in (WG_DMA, WG_DMA2):
                     name = f'wgrad6_kernel<{3 if v == WG_DMA else 2}>'
                 elif v == WG_PIPE:
                     name = f'wgrad2_kernel<{"true" if mode == IN_BNRELU else "false"}>'

@@ -139,6 +139,7 @@ int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
 #define BDN_WG_PIPE   2      /* software-pipelined bf16 kernel, operands staged through registers (BatchNorm+ReLU on load) */
 #define BDN_WG_DMA    3      /* bf16 kernel whose operands go HBM -> LDS by buffer_load ... lds (plain inputs only), 3 LDS buffers */
 #define BDN_WG_DMA2   4      /* the same with 2 LDS buffers (80 KB): leaves room for a convolution block on the same CU */
+#define BDN_WG_ROLE   5      /* role-split bf16 kernel: four MFMA waves + four staging waves (BatchNorm+ReLU on load or plain), 3 LDS buffers */
 #define BDN_WG_FLAGS(phases, kernel, blocks) ((phases) | ((kernel) << 8) | ((blocks) << 16))
 size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
                                     int in_mode, int flags);

@@ -755,8 +755,8 @@ def test_wgrad_phases_variant_and_per_call_flags():
     dt, td = DT['bf16']
     dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 91)))
     x = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 92)))
-    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, 0) in (2, 3)   # a pipelined kernel
-    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_BNRELU, 0) == WG_PIPE  # BatchNorm on load: register staging
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, 0) == 5        # the role-split kernel
+    assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, IN_BNRELU, 0) == 5       # also with BatchNorm on load
     assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, 16, 0, ipg, IN_PLAIN, 0) == WG_SIMPLE  # narrow input
     assert lib.bdn_conv3x3_wgrad_variant(dt, N, 8, 8, Cout, C0, 0, ipg, IN_PLAIN, 0) == WG_SIMPLE  # 8x8 maps
     assert lib.bdn_conv3x3_wgrad_variant(DT['fp32'][0], N, H, W, Cout, C0, 0, ipg, IN_PLAIN, 0) == WG_SIMPLE
@@ -796,7 +796,7 @@ def test_wgrad_kernel_variants_agree(mode):
     """Every weight-gradient kernel a shape may run gives the same dW up to the summation order of the partial tiles
     (ragged map, two statistic groups / two concatenated sources); with the same split plan the pipelined kernels are
     bit-identical to each other."""
-    from fabric_amd._lib import WG_DMA, WG_PIPE, WG_SIMPLE, wg_flags
+    from fabric_amd._lib import WG_DMA, WG_PIPE, WG_ROLE, WG_SIMPLE, wg_flags
     lib = _lib.load()
     N, H, W, Cout, ipg = 6, 37, 50, 128, 3
     dt, td = DT['bf16']
@@ -811,7 +811,7 @@ def test_wgrad_kernel_variants_agree(mode):
         x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C1, H, W), 198))) if C1 else None
         bn_d, in_mode = None, IN_PLAIN
     out, ran = {}, {}
-    for v in (WG_SIMPLE, WG_PIPE, WG_DMA):
+    for v in (WG_SIMPLE, WG_PIPE, WG_DMA, WG_ROLE):
         fl = wg_flags(3, v, 0)
         ran[v] = lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, C1, ipg, in_mode, fl)
         part = torch.empty(lib.bdn_wgrad_workspace_bytes_ex(dt, N, H, W, Cout, C0, C1, ipg, in_mode, fl) // 4, device='cuda')
@@ -823,6 +823,7 @@ def test_wgrad_kernel_variants_agree(mode):
         assert torch.isfinite(out[v]).all()
     assert ran[WG_SIMPLE] == WG_SIMPLE and ran[WG_PIPE] == WG_PIPE
     assert_close('pipelined vs simple', out[WG_PIPE], out[WG_SIMPLE], 2e-6)
+    assert ran[WG_ROLE] == WG_ROLE and torch.equal(out[WG_ROLE], out[WG_PIPE])    # role-split kernel: BatchNorm on load or plain
     if ran[WG_DMA] == WG_DMA:
         assert torch.equal(out[WG_DMA], out[WG_PIPE])
     else:

@@ -44,10 +44,12 @@ def test_argument_validation_needs_no_gpu():
     with pytest.raises(RuntimeError, match='4 GB'):       # 32-bit byte offsets inside the kernel: 4096 x 128 x 128 x 64 bf16 = 8 GB
         _lib.call('bdn_conv3x3', 1, 1, 64, None, 0, 0, None, 1, 1, None, 1, None, 4096, 128, 128, 64, None)
     # round-2 entry points: plans are pure functions of their arguments, errors come before anything touches a device
-    from fabric_amd._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_PIPE, WG_SIMPLE, wg_flags
+    from fabric_amd._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_PIPE, WG_ROLE, WG_SIMPLE, wg_flags
     var = lib.bdn_conv3x3_wgrad_variant
-    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) == WG_DMA
-    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_BNRELU, 0) == WG_PIPE
+    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) == WG_ROLE       # role-split kernel, plain operands by LDS-DMA
+    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_BNRELU, 0) == WG_ROLE      # ... BatchNorm+ReLU on load by its producer waves
+    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, wg_flags(kernel=WG_DMA)) == WG_DMA
+    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_BNRELU, wg_flags(kernel=WG_DMA)) == WG_ROLE   # the LDS-DMA kernel needs a plain operand
     assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, wg_flags(kernel=WG_PIPE)) == WG_PIPE
     assert var(BDN_F32, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) == WG_SIMPLE
     assert var(BDN_BF16, 128, 8, 8, 512, 512, 0, 64, IN_PLAIN, 0) == WG_SIMPLE

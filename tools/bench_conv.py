@@ -83,8 +83,8 @@ if what in ('wgrad', 'all'):
         line = f'{L.name:5s} wgrad N={n:3d} {h:3d}x{w:3d} Cin={c0 + c1:4d} Cout={L.cout:4d} '
         # every kernel the shape may run: register-staged pipeline (BatchNorm on load for the b layers), and the LDS-DMA
         # kernel on a plain operand (+ the one-off bdn_bnrelu pass that materialises it for the b layers)
-        for kern, kname in ((_lib.WG_PIPE, 'pipe'), (_lib.WG_DMA, 'dma')):
-            m = mode if kern == _lib.WG_PIPE else 0
+        for kern, kname in ((_lib.WG_PIPE, 'pipe'), (_lib.WG_DMA, 'dma'), (_lib.WG_ROLE, 'role')):
+            m = mode if kern != _lib.WG_DMA else 0
             flg = _lib.wg_flags(1, kern, 0)
             ran = lib.bdn_conv3x3_wgrad_variant(dt, n, h, w, L.cout, c0, c1, ipg, m, flg)
             fn = lambda: _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), L.cout, a0.data_ptr(), c0, a1.data_ptr() if c1 else None, c1,
