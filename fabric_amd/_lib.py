@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('BIDATE_LIB') or os.path.join(_HERE, 'csrc', 'libbidat
 
 BDN_F32, BDN_BF16, BDN_BF16X3 = 0, 1, 2
 IN_PLAIN, IN_BNRELU = 0, 1
-WG_SIMPLE, WG_PIPE, WG_DMA, WG_DMA2, WG_ROLE = 1, 2, 3, 4, 5
+WG_SIMPLE, WG_ROLE = 1, 5
 
 
 def wg_flags(phases=3, kernel=0, blocks=0):
@@ -28,8 +28,6 @@ SIGNATURES = {
     'bdn_pack_weights': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'bdn_pack_weights_multi': (_i, [_i, _vp, _i, _vp]),
     'bdn_conv3x3': (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'bdn_conv3x3_act_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    'bdn_conv3x3_act': (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_num_mtiles': (_i, [_i, _i, _i, _i, _i]),
     'bdn_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_wgrad': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -54,7 +52,6 @@ SIGNATURES = {
     'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_enc_skip_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'bdn_enc_skip_bwd_ex': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_enc_skip_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_outc_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_outc_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -63,7 +60,7 @@ SIGNATURES = {
     'bdn_outc_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_overlap_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),
     'bdn_bn_bwd_finalize': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -40,10 +40,6 @@ struct ConvArgs {
     // is bs_bn; the epilogue then also emits that layer's BatchNorm-backward partial sums (stats_partial, same
     // [n_mtiles][2][Cout] layout):  sum_p g  and  sum_p g*z  with  g = dA * [scale*z + shift > 0]
     const void* bs_z; const float* bs_bn;
-    // forward launches with BatchNorm+ReLU on load only: when non-null, the blocks of column tile 0 also WRITE the post-activation
-    // values they staged (their tile's interior pixels) to act_out [N,H,W,C0] -- relu(bn(z)) materialised for free for the
-    // weight-gradient GEMM of the same layer, whose LDS-DMA kernel needs a plain operand
-    void* act_out;
 };
 
 template <typename T> struct Mma;
@@ -108,9 +104,7 @@ struct ConvCfg {
 // ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
-// ACT: the variant that can also write the staged post-activation tensor (ConvArgs::act_out); a separate instantiation because
-// the extra live state spills in the register-tight variants (only the shapes of the 'b' convolutions that matter get one).
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool ACT = false, bool D3 = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
@@ -137,7 +131,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
 
     // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
     int p_pix[NPU];                                      // global pixel index of each unit (-1 = zero padding)
-    unsigned p_int = 0;                                  // bit i: unit i is an INTERIOR pixel of this tile (not halo) inside the image
     {
         // unit i of a thread is patch pixel tid/UPP + i*(256/UPP): walk (ti, yy, xx) incrementally instead of
         // dividing per unit (the divisions were a quarter of the prologue of the single-chunk layers)
@@ -151,7 +144,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
             const int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
             const bool ok = ti < TI && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
             p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
-            if (ACT) p_int |= (ok && yy >= 1 && yy <= TH && xx >= 1 && xx <= TW ? 1u : 0u) << i;
             xx += DX; yy += DY;
             if (xx >= TL::PW) { xx -= TL::PW; yy += 1; }
 #pragma unroll
@@ -160,7 +152,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
     }
     const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
     const unsigned p_subb = (unsigned)p_sub * CF::ES;
-    const bool write_act = ACT && a.act_out != nullptr && ntile == 0;
     // padding units load SOME valid pixel (zeroed at the store): pixel 0 of the tensor in 2-D; in 3x3x3 mode the sources are
     // shifted by a slice (pixel 0 of the lower one lies in front of the tensor), so the tile's own origin pixel
     const int p_fall = D3 ? (n0 * a.H + y0) * a.W + x0 : 0;
@@ -190,8 +181,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
         const int bc_ = D3 ? (c0_) - bs_ * a.C0 : (c0_);   /* channel inside its source */                \
         const bool dvs_ = !D3 || ((dmask >> bs_) & 1u);                                                 \
         const bool bn_ = a.in_bn != nullptr && (D3 || (c0_) < a.C0);                                    \
-        const bool wact_ = bn_ && write_act;               /* block-uniform */                           \
-        T* actp_ = reinterpret_cast<T*>(a.act_out) + (c0_) + p_sub;                                     \
         float sc_[EPU], sh_[EPU];                          /* all units of a thread share one channel group */ \
         if (bn_) {                                                                                      \
             const float* ps_ = bn_row(a.in_bn, grp, 2, a.C0) + bc_ + p_sub;                             \
@@ -206,12 +195,10 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
                 const bool ok_ = p_pix[i] >= 0 && dvs_;                                                 \
                 v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
                 *reinterpret_cast<uint4*>(pb_ + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = v_;          \
-                if (ACT && wact_ && ((p_int >> i) & 1u)) *reinterpret_cast<uint4*>(actp_ + (size_t)p_pix[i] * a.C0) = v_; \
             } else if (u_ < TL::NPIX * UPP) {              /* single-chunk kernels stage once, in the prologue */ \
                 uint4 v_ = make_uint4(0, 0, 0, 0);                                                      \
                 if (p_pix[i] >= 0 && dvs_) v_ = bn_ ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];      \
                 *reinterpret_cast<uint4*>(pb_ + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = v_;          \
-                if (ACT && wact_ && ((p_int >> i) & 1u)) *reinterpret_cast<uint4*>(actp_ + (size_t)p_pix[i] * a.C0) = v_; \
             }                                                                                           \
         }                                                                                               \
     }
@@ -493,21 +480,17 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
 static thread_local bool g_conv_query = false;
 static thread_local char g_conv_variant[160];
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool ACT = false, bool D3 = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
-    if (a.act_out != nullptr && !ACT) {
-        if (g_conv_query) { g_conv_variant[0] = 0; return BDN_E_SHAPE; }
-        BDN_FAIL(BDN_E_SHAPE, "conv3x3_act: this shape class has no activation-writing variant (ask bdn_conv3x3_act_supported)");
-    }
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     if (g_conv_query) {
         // the full template spelling, so that a profiler can match rocprofv3's kernel names exactly ("bf16" = unsigned short)
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s>",
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s>",
                  sizeof(T) == 2 ? "bf16" : "float", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false",
-                 sizeof(TO) == 2 ? "bf16" : "float", ACT ? "true" : "false", D3 ? "true" : "false");
+                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false");
         return BDN_OK;
     }
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, ACT, D3>;
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3>;
     BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
@@ -551,12 +534,6 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const bool one = (a.C0 + a.C1) * (int)sizeof(T) == CKB;
     // 64-wide outputs on 16x16 tiles: the single-chunk kernels (three blocks per CU share one L1) take the 2x2 wave
     // layout, whose waves stream half the filter bytes each (e1b: +9..12 %); with several chunks the 4x1 layout wins
-    constexpr bool ACTV = sizeof(T) == 2 && CKB == 128;   // activation-writing variants: bf16, 64-channel chunks, the three big shape classes
-    if (ACTV && a.act_out) {
-        if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true, T, ACTV>(a, g.n_mtiles, st);
-        if (g.TI == 1 && g.TH == 8 && p.BN == 128 && one) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, true, T, ACTV>(a, g.n_mtiles, st);
-        if (g.TI == 1 && g.TH == 8 && p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, false, T, ACTV>(a, g.n_mtiles, st);
-    }
     if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true>(a, g.n_mtiles, st);
     if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
     if (g.TI == 1) {
@@ -588,7 +565,7 @@ extern "C" int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_pe
 static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int C1,
                         int in_mode, const float* in_bn, int imgs_per_group,
                         const void* w, const float* bias, void* out, float* stats_partial,
-                        const void* bs_z, const float* bs_bn, void* act_out,
+                        const void* bs_z, const float* bs_bn,
                         int N, int H, int W, int Cout, void* stream) {
     if (!in0 || !w || !out) BDN_FAIL(BDN_E_ARG, "conv3x3: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
@@ -617,8 +594,6 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
     a.bs_z = bs_z; a.bs_bn = bs_bn; a.in2 = nullptr; a.Dz = 0;
-    if (act_out && (in_mode != BDN_IN_BNRELU || dtype == BDN_BF16X3)) BDN_FAIL(BDN_E_ARG, "conv3x3: act_out needs a BatchNorm+ReLU input");
-    a.act_out = act_out;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
@@ -644,32 +619,15 @@ extern "C" int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, 
                            const void* w, const float* bias, void* out, float* stats_partial,
                            int N, int H, int W, int Cout, void* stream) {
     return conv3x3_impl(dtype, in0, C0, in1, C1, in_mode, in_bn, imgs_per_group, w, bias, out, stats_partial,
-                        nullptr, nullptr, nullptr, N, H, W, Cout, stream);
+                        nullptr, nullptr, N, H, W, Cout, stream);
 }
 
-extern "C" int bdn_conv3x3_act(int dtype, const void* in0, int C0, const float* in_bn, int imgs_per_group,
-                               const void* w, const float* bias, void* out, float* stats_partial, void* act_out,
-                               int N, int H, int W, int Cout, void* stream) {
-    if (!in_bn || !act_out) BDN_FAIL(BDN_E_ARG, "conv3x3_act: null pointer");
-    return conv3x3_impl(dtype, in0, C0, nullptr, 0, BDN_IN_BNRELU, in_bn, imgs_per_group, w, bias, out, stats_partial,
-                        nullptr, nullptr, act_out, N, H, W, Cout, stream);
-}
-
-extern "C" int bdn_conv3x3_act_supported(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group) {
-    if (dtype != BDN_BF16 || N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C0 % 64 || Cout <= 0 || Cout % 64 || imgs_per_group <= 0 || N % imgs_per_group) return 0;
-    const ConvPlan p = conv_plan(N, H, W, Cout, imgs_per_group);
-    if (p.g.TI != 1) return 0;
-    if (p.g.TH == 16) return C0 == 64 ? 1 : 0;          // 64-wide outputs: the single-chunk kernel only
-    return p.BN == 128 ? 1 : 0;
-}
-
-extern "C" const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group, int act) {
+extern "C" const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group) {
     g_conv_variant[0] = 0;
     g_conv_query = true;
     void* dummy = reinterpret_cast<void*>(16);             // never dereferenced: nothing is launched in query mode
-    const int rc = conv3x3_impl(dtype, dummy, C0, C1 ? dummy : nullptr, C1, act ? BDN_IN_BNRELU : BDN_IN_PLAIN,
-                                act ? reinterpret_cast<const float*>(dummy) : nullptr, imgs_per_group, dummy, nullptr, dummy,
-                                nullptr, nullptr, nullptr, act ? dummy : nullptr, N, H, W, Cout, nullptr);
+    const int rc = conv3x3_impl(dtype, dummy, C0, C1 ? dummy : nullptr, C1, BDN_IN_PLAIN, nullptr, imgs_per_group, dummy, nullptr, dummy,
+                                nullptr, nullptr, nullptr, N, H, W, Cout, nullptr);
     g_conv_query = false;
     return rc == BDN_OK ? g_conv_variant : "";
 }
@@ -679,7 +637,7 @@ extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const voi
                                     int N, int H, int W, int Cout, void* stream) {
     if (!z_prev || !bn_prev || !bs_partial) BDN_FAIL(BDN_E_ARG, "conv3x3_dgrad_bs: null pointer");
     return conv3x3_impl(dtype, dz, C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group, w_dgrad, nullptr, dA, bs_partial,
-                        z_prev, bn_prev, nullptr, N, H, W, Cout, stream);
+                        z_prev, bn_prev, N, H, W, Cout, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -707,8 +665,8 @@ extern "C" int bdn_conv3d_num_mtiles(int N, int D, int H, int W) {
 
 template <typename T, int CKB>
 static int dispatch_conv3d(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
-    if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, false, T, false, true>(a, p.g.n_mtiles, st);
-    return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2, false, T, false, true>(a, p.g.n_mtiles, st);
+    if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, false, T, true>(a, p.g.n_mtiles, st);
+    return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2, false, T, true>(a, p.g.n_mtiles, st);
 }
 
 // in: [N,D,H,W,C]; w: bdn_pack_weights image of the OIHW view [Cout][3 C][3][3] whose input channel kd*C + c is tap kd of channel c
@@ -731,7 +689,7 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     a.C0 = C; a.C1 = C; a.ld0 = C; a.ld1 = C; a.Dz = D;
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group * D;
-    a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial; a.bs_z = nullptr; a.bs_bn = nullptr; a.act_out = nullptr;
+    a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial; a.bs_z = nullptr; a.bs_bn = nullptr;
     a.N = N * D; a.H = H; a.W = W; a.Cout = Cout;
     const ConvPlan p = conv3d_plan(N * D, H, W, Cout);
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_ntiles = 0;

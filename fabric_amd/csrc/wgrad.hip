@@ -199,276 +199,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void wgrad_kernel(Wgra
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// wgrad2: the bf16 / 8x16-tile / full 64-channel case (16 of the 18 layers of BiDateNet) as a software pipeline.
-// Same block tile (64 co x 64 ci x 9 taps, 4 waves, one block per CU), but
-//  * LDS is double buffered (2 x (patch 10x18 px + dz 128 px) x 192 B = 116 KB): ONE barrier per chunk, and the
-//    next chunk is staged while the current one is in the MFMAs;
-//  * global loads run TWO chunks ahead through two register sets (HBM latency is longer than one chunk of one
-//    wave per SIMD);
-//  * the MFMAs walk the patch ROW by ROW: the three fragments of patch row pr feed tile rows pr, pr-1, pr-2
-//    (taps r = 0, 1, 2), so every patch fragment is read from LDS once (30 fragment reads per chunk instead of
-//    72), and the reads of row pr+1 are issued ahead of the MFMAs of row pr;
-//  * every LDS read is one base register + an immediate offset, staging is branch free (masks, clamped
-//    addresses) and is spread over the rows so its VALU work sits in the shadow of the MFMAs.
-// LDS pixel stride: 128 B (the 64 channels, no padding) with a swizzle instead of the 192-byte padded stride: the two
-// 64-byte halves of a pixel row are swapped when bit 1 of the pixel index is set.  A transposing read touches four
-// consecutive pixels x one 64-byte half; with the swap their windows land on the four distinct bank quarters
-// (quarter = (2p + (h ^ bit1(p))) mod 4), so the reads stay conflict-free and a buffer pair takes 80 KB instead of 120 KB:
-// a second kernel's blocks fit beside this one's on a CU.
-struct Wg2 {
-    static constexpr int PW = 18, PH = 10, STR = 128;
-    static constexpr int PATCH_BYTES = 6 * 32 * STR;             // 180 patch pixels, padded to the 192 unit slots the staging threads own
-    static constexpr int DZ_BYTES = 128 * STR;
-    static constexpr int BUF = PATCH_BYTES + DZ_BYTES;
-    static constexpr int SMEM = 2 * BUF;
-};
-
-template <bool USE_BN>
-#ifndef WG2_OCC
-#define WG2_OCC 1
-#endif
-__global__ __launch_bounds__(256, WG2_OCC) void wgrad2_kernel(WgradArgs a) {
-    constexpr int PW = Wg2::PW, STR = Wg2::STR, BUF = Wg2::BUF, PATCH_BYTES = Wg2::PATCH_BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
-    const int half = lane >> 5, l31 = lane & 31;
-
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.n_cot * a.n_cit;
-    const int tile = logical % ntile, split = logical / ntile;
-    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
-    const int Cin = a.C0 + a.C1;
-
-    const bf16s* src; int Csrc, cs;
-    if (ci0 < a.C0) { src = reinterpret_cast<const bf16s*>(a.in0); Csrc = a.C0; cs = ci0; }
-    else { src = reinterpret_cast<const bf16s*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
-    const bf16s* dzp = reinterpret_cast<const bf16s*>(a.dz);
-
-    // ---- staging ownership: thread = (pixel lane u_pix, 16-byte channel unit sub); units i = u_pix + 32 i
-    const int u_pix = tid >> 3, sub = tid & 7, sub_e = sub * 8;
-    // LDS offset of unit 0 (unit i adds i*32*STR: 32 pixels further, same swizzle since bit 1 of the pixel index is unchanged)
-    const unsigned wbase = u_pix * STR + ((sub ^ (((u_pix >> 1) & 1) << 2)) * 16);
-    int pyx[6];                                                // patch units: (y-1, x-1) relative to the tile origin
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
-        pyx[i] = pix < Wg2::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
-    }
-    const int dpx = u_pix & 15, dpy0 = u_pix >> 4;             // dz units: tile pixel (dpy0 + 2 i, dpx)
-    // byte offsets from the chunk's uniform base pointers (32-bit: the dispatcher keeps tensors below 2^31 elements)
-    unsigned poff[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
-        poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + sub_e) * 2);
-    }
-    const unsigned poff_c = (unsigned)((((a.W + 1)) * Csrc + cs + sub_e) * 2);        // the tile's origin pixel: always inside
-    const unsigned drow = (unsigned)(a.W * a.Cout * 2);
-    const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + sub_e) * 2);
-    const unsigned doff_c = (unsigned)((co0 + sub_e) * 2);
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-
-    uint4 pA[6], dA[4], pB[6], dB[4];                          // the two prefetch register sets
-    unsigned mA = 0, mB = 0;                                   // validity bits: patch unit i -> bit i, dz unit i -> bit 8+i
-    int gA = 0, gB = 0;                                        // BatchNorm statistic group of each set's image
-    int cur_grp = -1;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) { sc[e] = 1.f; sh[e] = 0.f; }
-
-    const int q_begin = split * a.per_split;
-    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
-    int lq = q_begin;                                          // load cursor: chunk index and its tile coordinates
-    int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
-    int lg = ln / a.imgs_per_group;
-    int lpix = 0;
-
-    // issue the global loads of the NEXT chunk in sequence (chunks are always requested in order q_begin, +1, ...)
-    // into set (P, D, M, G).  Addresses are one uniform base (the tile's top-left halo pixel) plus a per-thread
-    // constant byte offset; out-of-image units load the tile's origin pixel instead and are zeroed by their mask
-    // bit when they are written to LDS.  The tile coordinates advance incrementally (no division per chunk).
-#define WG_LOAD(P, D, M, G)                                                                              \
-    {                                                                                                   \
-        const bool live_ = lq < q_end;                                                                  \
-        const int y0_ = lty * 8, x0_ = ltx * 16;                                                        \
-        const int pixbase_ = live_ ? (ln * a.H + y0_) * a.W + x0_ : lpix;   /* past the end: any valid tile, all units masked */ \
-        lpix = pixbase_;                                                                                \
-        const unsigned char* sp_ = reinterpret_cast<const unsigned char*>(src) + ((long)(pixbase_ - a.W - 1) * Csrc) * 2; \
-        const unsigned char* dp_ = reinterpret_cast<const unsigned char*>(dzp) + ((long)pixbase_ * a.Cout) * 2; \
-        if (live_) G = lg;                                                                              \
-        unsigned m_ = 0;                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 6; i++) {                                                  \
-            const int y_ = y0_ + (pyx[i] >> 16), x_ = x0_ + (short)(pyx[i] & 0xffff);                   \
-            const bool ok_ = live_ && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;     \
-            P[i] = *reinterpret_cast<const uint4*>(sp_ + (ok_ ? poff[i] : poff_c));                     \
-            m_ |= (ok_ ? 1u : 0u) << i;                                                                 \
-        }                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
-            const bool ok_ = live_ && (y0_ + dpy0 + 2 * i) < a.H && (x0_ + dpx) < a.W;                  \
-            D[i] = *reinterpret_cast<const uint4*>(dp_ + (ok_ ? doff0 + (unsigned)(2 * i) * drow : doff_c)); \
-            m_ |= (ok_ ? 1u : 0u) << (8 + i);                                                           \
-        }                                                                                               \
-        M = m_;                                                                                         \
-        if (live_) {                                                                                    \
-            lq++;                                                                                       \
-            if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
-        }                                                                                               \
-    }
-    // BatchNorm scale / shift rows of statistic group g_ for this thread's 8 channels (uniform branch, rare)
-#define WG_GROUP(g_)                                                                                     \
-    if (USE_BN && (g_) != cur_grp) {                                                                    \
-        cur_grp = (g_);                                                                                 \
-        const float* ps_ = bn_row(a.in_bn, cur_grp, 2, a.C0) + cs + sub_e;                              \
-        const float* ph_ = bn_row(a.in_bn, cur_grp, 3, a.C0) + cs + sub_e;                              \
-        _Pragma("unroll") for (int e = 0; e < 8; e++) { sc[e] = ps_[e]; sh[e] = ph_[e]; }                \
-    }
-    // write one unit of a register set into LDS buffer `wb_` (byte address of the buffer)
-#define WG_ST_P(P, M, i_, wb_)                                                                           \
-    {                                                                                                   \
-        uint4 v_ = P[i_];                                                                               \
-        if (USE_BN) v_ = bnrelu_unit<bf16s>(v_, sc, sh);                                                \
-        const bool ok_ = ((M) >> (i_)) & 1u;                                                            \
-        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-        *reinterpret_cast<uint4*>((wb_) + wbase + (i_) * 32 * STR) = v_;                                \
-    }
-#define WG_ST_D(D, M, i_, wb_)                                                                           \
-    {                                                                                                   \
-        uint4 v_ = D[i_];                                                                               \
-        const bool ok_ = ((M) >> (8 + (i_))) & 1u;                                                      \
-        v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-        *reinterpret_cast<uint4*>((wb_) + PATCH_BYTES + wbase + (i_) * 32 * STR) = v_;                  \
-    }
-
-    // ---- MFMA operand addressing: lane's transposing-read role = pixel kpix of a 4-pixel group, 4-channel piece
-    // (lane&3) of 16-channel block ((lane>>4)&1) of the wave's 32 channels
-    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const int kpix = (lane & 15) >> 2;
-    // dz rows: pixel index ks*16 + half*8 + kpix (+4): bit 1 is bit 1 of kpix -> one swizzled base
-    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;   // + ks*16*STR (+4*STR)
-    // patch rows: pixel index pr*18 + 8*half + kpix + c (+4): bit 1 is bit 1 of (kpix + m), m = (c + 2 pr) & 3 -> four bases
-    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
-    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
-    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
-#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
-    uint4 af[4], bq[2][3];
-#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
-#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
-    // patch row pr_: prefetch the fragments of row pr_+1 (and dz row pr_+1), then the MFMAs of every (tile row, r)
-    // pair that reads patch row pr_, then this row's share of the staging (STG_)
-#define WG_ROW(pr_, STG_)                                                                                \
-    {                                                                                                   \
-        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
-        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) }                     \
-        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
-        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) }       \
-        STG_                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-    }
-    // one chunk: compute from buffer rb_, stage set (P, D, M, G) (chunk q+1) into buffer wb_, then refill that set
-    // with the next chunk in sequence (q+3)
-#define WG_CHUNK(rb_, wb_, P, D, M, G)                                                              \
-    {                                                                                                   \
-        const unsigned char* rb = (rb_);                                                                \
-        unsigned char* wb = (wb_);                                                                      \
-        WG_GROUP(G)                                                                                     \
-        LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)                        \
-        WG_ROW(0, )                                                                                     \
-        WG_ROW(1, )                                                                                     \
-        WG_ROW(2, WG_ST_P(P, M, 0, wb) WG_ST_P(P, M, 1, wb))                                            \
-        WG_ROW(3, WG_ST_P(P, M, 2, wb) WG_ST_P(P, M, 3, wb))                                            \
-        WG_ROW(4, WG_ST_P(P, M, 4, wb) WG_ST_P(P, M, 5, wb))                                            \
-        WG_ROW(5, WG_ST_D(D, M, 0, wb) WG_ST_D(D, M, 1, wb))                                            \
-        WG_ROW(6, WG_ST_D(D, M, 2, wb) WG_ST_D(D, M, 3, wb))                                            \
-        WG_ROW(7, WG_LOAD(P, D, M, G))                                                             \
-        WG_ROW(8, )                                                                                     \
-        WG_ROW(9, )                                                                                     \
-    }
-
-    unsigned char* buf0 = smem;
-    unsigned char* buf1 = smem + BUF;
-    if (q_begin < q_end) {
-        WG_LOAD(pA, dA, mA, gA)
-        WG_LOAD(pB, dB, mB, gB)
-        WG_GROUP(gA)
-#pragma unroll
-        for (int i = 0; i < 6; i++) WG_ST_P(pA, mA, i, buf0)
-#pragma unroll
-        for (int i = 0; i < 4; i++) WG_ST_D(dA, mA, i, buf0)
-        WG_LOAD(pA, dA, mA, gA)
-        __syncthreads();
-        for (int q = q_begin; q < q_end; q += 2) {
-            WG_CHUNK(buf0, buf1, pB, dB, mB, gB)
-            __syncthreads();
-            WG_CHUNK(buf1, buf0, pA, dA, mA, gA)   // an odd tail runs on an all-zero chunk (masks are clear past q_end)
-            __syncthreads();
-        }
-    }
-#undef WG_LOAD
-#undef WG_GROUP
-#undef WG_ST_P
-#undef WG_ST_D
-#undef TRP
-#undef LDA
-#undef LDB
-#undef B_BASE
-#undef WG_MMA
-#undef WG_ROW
-#undef WG_CHUNK
-
-    // partial[split][tap][co][ci]: one uniform base per (tap, row group) + the lane's fixed element offset, so the 144
-    // stores need no per-store 64-bit address arithmetic (it was a thousand VALU instructions per block)
-    const int ci = ci0 + wn * 32 + l31;
-    if (ci < Cin) {
-        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);                 // elements; co0 is in the base
-        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;                 // wave-uniform
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
-        }
-    }
-}
-
-template <bool USE_BN>
-static int launch_wgrad2(const WgradArgs& a, hipStream_t st) {
-    auto kern = wgrad2_kernel<USE_BN>;
-    BDN_SET_SMEM_ONCE(kern, Wg2::SMEM, "wgrad2");
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), Wg2::SMEM, st, a);
-    BDN_CHECK_LAUNCH("wgrad2");
-    return BDN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// wgrad6 (BDN_WG_DMA): wgrad2's tile, split plan, LDS image and MFMA order (results are bit-identical), but the operands
-// never pass through registers: both the dz tile and the activation halo patch go HBM/L2 -> LDS by
-// `buffer_load_dwordx4 ... lds` (LDS-DMA).  wgrad2's anatomy showed that with one wave per SIMD every
-// staging instruction -- global loads into the prefetch sets, mask selects, ds_write_b128 -- is time the matrix pipe
-// idles (staging = 40 % of the kernel).  Here a chunk costs each wave ten DMA instructions and ~70 VALU of address masks:
-//   * an LDS-DMA writes lane l's 16 bytes to (M0 base + 16 l): the image must be lane-linear, so wgrad2's bank swizzle
-//     (64-byte halves of a pixel swapped when bit 1 of the pixel index is set) moves to the SOURCE side -- lane (pixel p,
-//     slot s) fetches channel unit s ^ 4*bit1(p).  Same involution on the read side as before, identical LDS contents.
-//   * zero padding / ragged tiles / chunks past the split's end: the lane's offset is replaced by one beyond the buffer
-//     descriptor's num_records; the out-of-range load returns 0 and the DMA writes that 0 (tools/probe_dma.hip).
-//   * the descriptor base is re-pointed at every chunk's top-left halo pixel (scalar ALU), so the per-lane offsets are
-//     chunk-invariant constants.
-//   * THREE LDS buffers (120 KB): the DMAs of chunk q+2 are issued during chunk q (HBM latency under load exceeds one
-//     chunk), `s_waitcnt vmcnt(10)` + one raw s_barrier per chunk hand chunk q+1 to the readers and free buffer q-1.
-// The input must be plain (no BatchNorm+ReLU on load): the training schedule materialises relu(bn(z)) once per layer on
-// the weight-gradient stream (bdn_bnrelu) instead of re-deriving it in each of the Cout/64 column-tile blocks.
+// LDS image of the pipelined weight-gradient kernel, per chunk buffer: the halo patch (10 x 18 pixels, padded to 192) and the
+// dz tile (128 pixels), 128 bytes (64 channels) per pixel, no padding: the two 64-byte halves of a pixel are swapped when bit 1
+// of the pixel index is set, so the four consecutive pixels a transposing read touches land on the four bank quarters.
 struct Wg6 {
     static constexpr int PW = 18, PH = 10, STR = 128;
     static constexpr int PATCH_BYTES = 6 * 32 * STR;             // 180 patch pixels padded to 192 (24 DMA pieces of 8 pixels)
@@ -478,10 +211,11 @@ struct Wg6 {
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-// one LDS-DMA piece: every lane's 16 bytes at (descriptor base + voff) -> LDS byte (lds_dst + 16 lane).  Inline asm on
-// purpose: hipcc's wait-count pass drains the VM queue (vmcnt(0)) before the next ds_read behind an LDS-DMA it can see,
-// which serialises the pipeline; this one is invisible to it and is waited for by hand (vmcnt(N) + barrier).  M0 (the
-// DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
+// one LDS-DMA piece: every lane's 16 bytes at (descriptor base + voff) -> LDS byte (lds_dst + 16 lane); a lane whose offset lies
+// beyond the descriptor's num_records reads 0, and the DMA writes that 0 (tools/probe_dma.hip) -- zero padding, ragged tiles and
+// chunks past a split's end cost no instruction.  Inline asm on purpose: hipcc's wait-count pass drains the VM queue (vmcnt(0))
+// before the next LDS access behind an LDS-DMA it can see, which serialises the pipeline; this one is invisible to it and is
+// waited for by hand.  M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
 __device__ __forceinline__ void lds_dma16(u32x4_t rsrc, unsigned lds_dst, unsigned voff) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -493,201 +227,14 @@ __device__ __forceinline__ u32x4_t raw_rsrc(const void* base, unsigned num_recor
     return r;
 }
 
-// NBUF = 3: chunk q+2 is fetched during chunk q (120 KB of LDS: the kernel owns its CU).  NBUF = 2: chunk q+1 during chunk q, all
-// ten pieces issued in the first five rows (80 KB and 224 registers per lane: a block of the data-gradient / forward convolution
-// -- 55-61 KB, <= 256 registers -- fits on the same CU, so the two MFMA kernels of the two streams share the matrix pipe).
-template <int NBUF>
-__global__ __launch_bounds__(256, 1) void wgrad6_kernel(WgradArgs a) {
-    constexpr int PW = Wg6::PW, STR = Wg6::STR, BUF = Wg6::BUF, PATCH_BYTES = Wg6::PATCH_BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
-    const int half = lane >> 5, l31 = lane & 31;
-
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.n_cot * a.n_cit;
-    const int tile = logical % ntile, split = logical / ntile;
-    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
-    const int Cin = a.C0 + a.C1;
-
-    const unsigned char* src; int Csrc, cs;
-    if (ci0 < a.C0) { src = reinterpret_cast<const unsigned char*>(a.in0); Csrc = a.C0; cs = ci0; }
-    else { src = reinterpret_cast<const unsigned char*>(a.in1); Csrc = a.C1; cs = ci0 - a.C0; }
-    const unsigned char* dzp = reinterpret_cast<const unsigned char*>(a.dz);
-
-    // ---- DMA ownership: wave w, piece i = LDS pixels 8w + 32i .. +7; lane = (pixel u_pix of the piece, 16-byte slot sub)
-    const int u_pix = wave * 8 + (lane >> 3), sub = lane & 7;
-    const int unit = sub ^ (((u_pix >> 1) & 1) << 2);           // source channel unit of this LDS slot (pieces keep bit 1 of the pixel)
-    int pyx[6];                                                // patch pixel: (y-1, x-1) relative to the tile origin
-    unsigned poff[6];                                          // its byte offset from the chunk's top-left halo pixel
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
-        pyx[i] = pix < Wg6::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);   // never inside
-        poff[i] = (unsigned)(((yy * a.W + xx) * Csrc + cs + unit * 8) * 2);
-    }
-    const int dpx = u_pix & 15, dpy0 = u_pix >> 4;             // dz pieces: tile pixel (dpy0 + 2 i, dpx)
-    const unsigned drow2 = (unsigned)(2 * a.W * a.Cout * 2);
-    const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * a.Cout + co0 + unit * 8) * 2);
-    const unsigned lds_piece0 = (unsigned)(wave * 8 * STR);     // + 32 i STR (+ PATCH_BYTES for dz) + buffer offset
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-
-    const int q_begin = split * a.per_split;
-    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
-    int lq = q_begin;                                          // DMA cursor: chunk index and its tile coordinates
-    int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
-    int ldep = a.Dz ? ln % a.Dz : 0;                           // 3x3x3 mode: depth index of slice ln inside its sample
-    const long dslice = (long)a.dshift * a.H * a.W;            // pixels between a dz slice and its partner activation slice
-    // per-chunk state of the DMA issue (set by W6_BEGIN, used by the W6_P / W6_D pieces spread over the MFMA rows)
-    u32x4_t rs_p = {0, 0, 0, 0}, rs_d = {0, 0, 0, 0};
-    int cy0 = 0, cx0 = 0; bool clive = false;
-    unsigned cwb = 0;
-    const unsigned smem_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);   // LDS byte address
-
-#define W6_BEGIN(wb_)                                                                                    \
-    {                                                                                                   \
-        const bool inside_ = lq < q_end;                                                                \
-        clive = inside_ && (a.Dz == 0 || (unsigned)(ldep + a.dshift) < (unsigned)a.Dz);                  \
-        cy0 = lty * 8; cx0 = ltx * 16; cwb = (wb_);                                                      \
-        const long pixbase_ = clive ? (long)(ln * a.H + cy0) * a.W + cx0 : 0;                           \
-        rs_p = raw_rsrc(src + (pixbase_ + (clive ? dslice : 0) - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS); \
-        rs_d = raw_rsrc(dzp + pixbase_ * a.Cout * 2, Wg6::NUM_RECORDS);                                 \
-        if (inside_) { lq++; if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (++ldep == a.Dz) ldep = 0; } } } \
-    }
-#define W6_P(i_)                                                                                         \
-    {                                                                                                   \
-        const int y_ = cy0 + (pyx[i_] >> 16), x_ = cx0 + (short)(pyx[i_] & 0xffff);                     \
-        const bool ok_ = clive && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W;         \
-        lds_dma16(rs_p, smem_base + cwb + lds_piece0 + (i_) * 32 * STR, ok_ ? poff[i_] : Wg6::OOB);      \
-    }
-#define W6_D(i_)                                                                                         \
-    {                                                                                                   \
-        const bool ok_ = clive && (cy0 + dpy0 + 2 * (i_)) < a.H && (cx0 + dpx) < a.W;                   \
-        lds_dma16(rs_d, smem_base + cwb + PATCH_BYTES + lds_piece0 + (i_) * 32 * STR,                   \
-                  ok_ ? doff0 + (unsigned)(i_) * drow2 : Wg6::OOB);                                      \
-    }
-
-    // ---- MFMA operand addressing: identical to wgrad2 (same LDS image)
-    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const int kpix = (lane & 15) >> 2;
-    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;
-    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
-    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
-    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
-#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
-    uint4 af[4], bq[2][3];
-#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
-#define LDA(dst_, ks_) { const uint2 l_ = TRP(rb + a_base + (ks_) * 16 * STR), h_ = TRP(rb + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define LDB(dst_, pr_, c_) { const uint2 l_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP(rb + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
-#define WG_MMA(t_, ks_, pr_, c_) acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[(ks_) & 3]), __builtin_bit_cast(bf16x8, bq[(pr_) & 1][c_]), acc[t_], 0, 0, 0);
-#define WG_ROW(pr_, STG_)                                                                                \
-    {                                                                                                   \
-        if ((pr_) + 1 < 10) { LDB(bq[((pr_) + 1) & 1][0], (pr_) + 1, 0) LDB(bq[((pr_) + 1) & 1][1], (pr_) + 1, 1) LDB(bq[((pr_) + 1) & 1][2], (pr_) + 1, 2) } \
-        if ((pr_) + 1 < 8) { LDA(af[((pr_) + 1) & 3], (pr_) + 1) }                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((pr_) < 8) { WG_MMA(0, (pr_), (pr_), 0) WG_MMA(1, (pr_), (pr_), 1) WG_MMA(2, (pr_), (pr_), 2) }                     \
-        if ((pr_) >= 1 && (pr_) < 9) { WG_MMA(3, (pr_) - 1, (pr_), 0) WG_MMA(4, (pr_) - 1, (pr_), 1) WG_MMA(5, (pr_) - 1, (pr_), 2) } \
-        if ((pr_) >= 2) { WG_MMA(6, (pr_) - 2, (pr_), 0) WG_MMA(7, (pr_) - 2, (pr_), 1) WG_MMA(8, (pr_) - 2, (pr_), 2) }       \
-        STG_                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-    }
-
-    if (q_begin < q_end) {
-        // prologue: chunk q_begin (and, three buffers, q_begin + 1) on their way into buffers 0 (and 1)
-        W6_BEGIN(0)
-#pragma unroll
-        for (int i = 0; i < 6; i++) W6_P(i)
-#pragma unroll
-        for (int i = 0; i < 4; i++) W6_D(i)
-        if constexpr (NBUF == 3) {
-            W6_BEGIN(BUF)
-#pragma unroll
-            for (int i = 0; i < 6; i++) W6_P(i)
-#pragma unroll
-            for (int i = 0; i < 4; i++) W6_D(i)
-        }
-        unsigned cur = 0, nxt = (NBUF - 1) * BUF;              // byte offsets of the buffer read now / filled for chunk q + NBUF - 1
-        for (int q = q_begin; q < q_end; q++) {
-            // chunk q has landed (three buffers: this wave's ten older DMAs; chunk q+1's ten may still fly); after the barrier
-            // every wave's have, and nobody reads the buffer of chunk q-1 any more -- which is where the next fetch goes
-            if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const unsigned char* rb = smem + cur;
-            W6_BEGIN(nxt)
-            LDB(bq[0][0], 0, 0) LDB(bq[0][1], 0, 1) LDB(bq[0][2], 0, 2) LDA(af[0], 0)
-            if constexpr (NBUF == 3) {
-                WG_ROW(0, W6_P(0))
-                WG_ROW(1, W6_P(1))
-                WG_ROW(2, W6_P(2))
-                WG_ROW(3, W6_P(3))
-                WG_ROW(4, W6_P(4))
-                WG_ROW(5, W6_P(5))
-                WG_ROW(6, W6_D(0))
-                WG_ROW(7, W6_D(1))
-                WG_ROW(8, W6_D(2))
-                WG_ROW(9, W6_D(3))
-            } else {
-                WG_ROW(0, W6_P(0) W6_P(1))
-                WG_ROW(1, W6_P(2) W6_P(3))
-                WG_ROW(2, W6_P(4) W6_P(5))
-                WG_ROW(3, W6_D(0) W6_D(1))
-                WG_ROW(4, W6_D(2) W6_D(3))
-                WG_ROW(5, )
-                WG_ROW(6, )
-                WG_ROW(7, )
-                WG_ROW(8, )
-                WG_ROW(9, )
-            }
-            cur = cur == (NBUF - 1) * BUF ? 0 : cur + BUF;
-            nxt = nxt == (NBUF - 1) * BUF ? 0 : nxt + BUF;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (all-zero) fetches: nothing may land after exit
-    }
-#undef W6_BEGIN
-#undef W6_P
-#undef W6_D
-#undef TRP
-#undef LDA
-#undef LDB
-#undef B_BASE
-#undef WG_MMA
-#undef WG_ROW
-
-    // partial[split][tap][co][ci], as wgrad2
-    const int ci = ci0 + wn * 32 + l31;
-    if (ci < Cin) {
-        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
-        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
-        }
-    }
-}
-
-template <int NBUF>
-static int launch_wgrad6(const WgradArgs& a, hipStream_t st) {
-    auto kern = wgrad6_kernel<NBUF>;
-    BDN_SET_SMEM_ONCE(kern, NBUF * Wg6::BUF, "wgrad6");
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), NBUF * Wg6::BUF, st, a);
-    BDN_CHECK_LAUNCH("wgrad6");
-    return BDN_OK;
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// wgrad7 (BDN_WG_ROLE): wgrad6's tile, LDS image, split plan and MFMA order (results bit-identical to wgrad2 / wgrad6) with the
-// block split by ROLE -- made for the half-chip grid, where a weight-gradient block owns its CU anyway:
+// wgrad7 (BDN_WG_ROLE): the bf16 / 8x16-tile / full 64-channel case (16 of the 18 layers of BiDateNet).  Block tile 64 (co) x 64 (ci)
+// x all nine taps (9 accumulators per MFMA wave), a contiguous range of 128-pixel chunks per block, three LDS chunk buffers (120 KB),
+// ONE barrier per chunk.  The MFMAs walk the patch ROW by ROW: the three fragments of patch row pr feed tile rows pr, pr-1, pr-2 (taps
+// r = 0, 1, 2), so every patch fragment is read from LDS once (30 fragment reads per chunk instead of 72) and the reads of row pr+1
+// are issued ahead of the MFMAs of row pr (ds_read_b64_tr_b16: lane-group semantics pinned by tools/probe_hw.hip).
+// The block is split by ROLE -- made for the half-chip grid, where a weight-gradient block owns its CU anyway (the retired four-wave
+// kernels wgrad2 / wgrad6, tools/experimental/wgrad_v2_v6.hip.inc, compute the same values bit for bit):
 //   waves 0-3  CONSUMERS, one per SIMD: 76 transposing fragment reads + 72 MFMAs per chunk and nothing else;
 //   waves 4-7  PRODUCERS, one per SIMD beside a consumer: everything that stalls a lone MFMA wave in wgrad2 -- the global
 //              loads of the halo patch (two chunks ahead, through two register sets), BatchNorm+ReLU of the producing layer,
@@ -769,15 +316,18 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
         int lq = q_begin;
         int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
         int lg = ln / a.imgs_per_group;
+        int ldep = a.Dz ? ln % a.Dz : 0;                           // 3x3x3 mode: depth index of slice ln inside its sample
+        const long dslice = (long)a.dshift * a.H * a.W;            // pixels between a dz slice and its partner activation slice
         bool c_live = false; int c_y0 = 0, c_x0 = 0, c_grp = 0; long c_pix = 0;
 #define W7_CUR()                                                                                         \
         {                                                                                               \
-            c_live = lq < q_end;                                                                        \
+            const bool inside_ = lq < q_end;                 /* a chunk whose partner slice lies outside the sample is skipped (all zero) */ \
+            c_live = inside_ && (a.Dz == 0 || (unsigned)(ldep + a.dshift) < (unsigned)a.Dz);            \
             c_y0 = lty * 8; c_x0 = ltx * 16;                                                            \
             if (c_live) { c_pix = (long)(ln * a.H + c_y0) * a.W + c_x0; c_grp = lg; }                   \
-            if (c_live) {                                                                               \
+            if (inside_) {                                                                              \
                 lq++;                                                                                   \
-                if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
+                if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; if (++ldep == a.Dz) ldep = 0; if (ln - lg * a.imgs_per_group == a.imgs_per_group) lg++; } } \
             }                                                                                           \
         }
         // dz tile of the evaluated chunk -> buffer at byte offset wb_ (4 LDS-DMA pieces per wave)
@@ -792,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
         // plain halo patch of the evaluated chunk -> buffer wb_ (6 LDS-DMA pieces per wave)
 #define W7_DMA_P(wb_)                                                                                    \
         {                                                                                               \
-            const u32x4_t rs_ = raw_rsrc(src + (c_pix - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS);         \
+            const u32x4_t rs_ = raw_rsrc(src + (c_pix + dslice - a.W - 1) * Csrc * 2, Wg6::NUM_RECORDS); \
             _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
                 const int y_ = c_y0 + (pyx[i] >> 16), x_ = c_x0 + (short)(pyx[i] & 0xffff);             \
                 const bool ok_ = c_live && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W; \
@@ -802,7 +352,7 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
         // halo patch of the evaluated chunk -> register set (P, M, G): six global loads per lane
 #define W7_LOAD_P(P, M, G)                                                                               \
         {                                                                                               \
-            const unsigned char* sp_ = src + (c_pix - a.W - 1) * Csrc * 2;                              \
+            const unsigned char* sp_ = src + (c_pix + dslice - a.W - 1) * Csrc * 2;                     \
             if (c_live) G = c_grp;                                                                      \
             unsigned m_ = 0;                                                                            \
             _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
@@ -891,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
         return;
     }
 
-    // ===================================================== consumer: wgrad2's row walk, fragment reads and MFMAs only
+    // ===================================================== consumer: the row walk, fragment reads and MFMAs only
     const int wm = wave >> 1, wn = wave & 1;                  // wave tile: co [wm*32,+32) x ci [wn*32,+32)
     const int half = lane >> 5, l31 = lane & 31;
     f32x16 acc[9];
@@ -1195,7 +745,7 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 // ---- plan: tile geometry, split count, kernel variant.  A pure function of the shape and of the caller's `flags` word
 // (no process-wide tuning state: two threads may size and launch different plans concurrently).
 //   flags bits 0-1   phases (bdn_conv3x3_wgrad_ex)
-//   flags bits 8-11  kernel override: 0 = the library's choice, BDN_WG_SIMPLE / BDN_WG_PIPE / BDN_WG_DMA force one where the shape allows
+//   flags bits 8-11  kernel override: 0 = the library's choice, BDN_WG_SIMPLE forces the one-chunk-at-a-time kernel
 //   flags bits 16-28 target grid size of the GEMM (0 = default, one block per CU)
 #ifndef WG_SIMPLE_MULT
 #define WG_SIMPLE_MULT 2
@@ -1214,15 +764,8 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
     const bool pipe_ok = dtype == BDN_BF16 && !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 && C1 % 64 == 0 &&
                          (size_t)N * H * W * cmax < ((size_t)1 << 31);
     const int want = (flags >> 8) & 15;
-    // LDS-DMA kernel: plain inputs only (no BatchNorm+ReLU on load), and every image row / channel run must be addressable
-    // with 32-bit byte offsets from a chunk's halo origin (always true below 2^31 elements)
-    const bool dma_ok = pipe_ok && in_mode == BDN_IN_PLAIN;
-    p.variant = pipe_ok ? BDN_WG_ROLE : BDN_WG_SIMPLE;      // role-split kernel: +10 % over the LDS-DMA kernel on plain operands, 1.5x wgrad2 with BatchNorm on load
-    if (want == BDN_WG_DMA && dma_ok) p.variant = BDN_WG_DMA;
+    p.variant = pipe_ok ? BDN_WG_ROLE : BDN_WG_SIMPLE;
     if (want == BDN_WG_SIMPLE) p.variant = BDN_WG_SIMPLE;
-    if (want == BDN_WG_PIPE && pipe_ok) p.variant = BDN_WG_PIPE;
-    if (want == BDN_WG_DMA2 && dma_ok) p.variant = BDN_WG_DMA2;
-    if (want == BDN_WG_ROLE && pipe_ok) p.variant = BDN_WG_ROLE;
     // the simple kernel (first layer / 8x8 maps / f32) has no software pipeline: it hides latency with a second block per CU
     int blocks = (flags >> 16) & 0x1fff;
     if (blocks == 0) blocks = 128;                          // HALF the CUs: the GEMM runs beside the dz chain on a second stream, and two MFMA kernels
@@ -1315,10 +858,7 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     int rc = BDN_OK;
     if (!(phases & 1)) {
     } else if (dtype == BDN_BF16) {
-        if (p.variant == BDN_WG_DMA) rc = launch_wgrad6<3>(a, st);
-        else if (p.variant == BDN_WG_DMA2) rc = launch_wgrad6<2>(a, st);
-        else if (p.variant == BDN_WG_ROLE) rc = a.in_bn ? launch_wgrad7<true>(a, st) : launch_wgrad7<false>(a, st);
-        else if (p.variant == BDN_WG_PIPE) rc = a.in_bn ? launch_wgrad2<true>(a, st) : launch_wgrad2<false>(a, st);
+        if (p.variant == BDN_WG_ROLE) rc = a.in_bn ? launch_wgrad7<true>(a, st) : launch_wgrad7<false>(a, st);
         else if (p.ksplit) rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 8, 2, true>(a, st);
         else rc = p.g.TI == 1 ? launch_wgrad<bf16s, 8, 16, 1, false>(a, st) : launch_wgrad<bf16s, 8, 8, 2, false>(a, st);
     } else {
@@ -1372,7 +912,7 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
     return BDN_OK;
 }
 
-// which kernel the GEMM phase runs for `flags` (bench.py names its roofline line after it): BDN_WG_SIMPLE / BDN_WG_PIPE / ...
+// which kernel the GEMM phase runs for `flags` (bench.py names its roofline line after it): BDN_WG_SIMPLE / BDN_WG_ROLE
 extern "C" int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || imgs_per_group <= 0) return 0;
     if (dtype == BDN_BF16X3) return wgrad_plan(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags).variant;
@@ -1404,7 +944,7 @@ extern "C" int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void*
         a.dshift = kd - 1;
         int rc;
         if (dtype == BDN_BF16) {
-            if (p.variant == BDN_WG_DMA) rc = launch_wgrad6<3>(a, st);
+            if (p.variant == BDN_WG_ROLE) rc = launch_wgrad7<false>(a, st);
             else rc = p.ksplit ? launch_wgrad<bf16s, 8, 16, 1, true>(a, st) : launch_wgrad<bf16s, 8, 16, 1, false>(a, st);
         } else {
             rc = p.ksplit ? launch_wgrad<float, 8, 16, 1, true>(a, st) : launch_wgrad<float, 8, 16, 1, false>(a, st);

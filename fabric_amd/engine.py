@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from ._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_DMA2, WG_PIPE, WG_ROLE, call, ptr, wg_flags
+from ._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_ROLE, call, ptr, wg_flags
 
 ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
@@ -130,10 +130,7 @@ class Workspace:
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
         self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, 256)) // 4
-        self.n_act = max(self.z[L.name].numel() for L in eng.layers if L.name.endswith('a'))
         self._bwd = None
-        self.act = {}              # data_ptr of an 'a' conv's z -> its materialised relu(bn(z)) (written by the following conv's forward)
-        self.act_valid = set()
         self._split = {}
         self._outc_ws = None
         self.logits = None
@@ -161,7 +158,6 @@ class Workspace:
             self._bwd = dict(bnb=torch.empty(self.n_bnb, dtype=torch.float32, device=device),
                              wg=torch.empty(self.n_wg, dtype=torch.float32, device=device),
                              wg1=torch.empty(self.n_wg1, dtype=torch.float32, device=device),
-                             act=torch.empty(self.n_act, dtype=self.x0.dtype, device=device),
                              sums=torch.empty(2 * 2 * 1024, dtype=torch.float32, device=device))
         return self._bwd
 
@@ -182,7 +178,6 @@ class BiDateEngine:
         self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32                  # storage type: what the HBM-bound kernels see
         self.mdt = BDN_BF16X3 if precision == 'bf16x3' else self.dt             # what the GEMM kernels (conv3x3, wgrad, weight packing) see
         self.x3 = precision == 'bf16x3'
-        self.x3_side_stream = True      # A/B switch: bf16x3 weight gradients on the second stream too (own operand-split buffers)
         self.tdtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.esize = 2 if precision == 'bf16' else 4
         self.cp = _round_up(n_channels, 16)
@@ -193,32 +188,13 @@ class BiDateEngine:
         self._pack_desc = None
         self._packed_versions = None
         self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
-        self.fuse_head_bwd = True       # A/B switch: d4b's BatchNorm backward recomputes the classifier's data gradient from dlogits
-        self.fuse_first_wgrad = True    # A/B switch: the first conv's BatchNorm backward inside its weight-gradient GEMM (bf16 only)
-        self.fuse_bn_bwd_stats = True   # A/B switch (tools/ab_step.py): BatchNorm-backward sums in the producer's epilogue
-        self.wgrad_dma = False          # A/B switch: relu(bn(z)) of the 'a' convs is materialised once on the weight-gradient stream and
-                                        # the following conv's weight-gradient GEMM takes the LDS-DMA kernel (plain operands only).
-                                        # The 'a' layers (plain inputs) take that kernel anyway; for the 'b' layers the extra HBM pass
-                                        # costs the step more than the faster GEMM returns (6.37 vs 6.29 ms), so they keep
-                                        # BatchNorm-on-load in the register-staged kernel
-        self.enc_two_pass = False       # A/B switch: the encoder's skip / unpool backward as sums pass + fused apply pass (dA never written:
-                                        # 22 % fewer bytes, bit-identical dz -- but the kernel's argmax / product work runs twice: +1.9 % step)
-        self.fwd_writes_act = False     # A/B switch (bf16; measured +0.6 % step time: the stores cost the chain what the faster GEMM saves beside it): the training forward of a 'b' conv also writes the relu(bn(z)) tile it stages
-                                        # (bdn_conv3x3_act), so that layer's weight-gradient GEMM gets a plain operand (LDS-DMA kernel)
-                                        # without any extra pass
-        self.wgrad_kernel = 0           # A/B: per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
-        self.wgrad_blocks = 0           # A/B: per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
-        self.wgrad_blocks_tail = 0      # A/B: the same for the LAST GEMMs of backward (e1b, e2a): the chain has almost ended by then
-        self.wgrad_tail_layers = ('e1b',)
-        self.wgrad_sched = 0            # how the weight-gradient GEMMs are placed beside the dz chain (both are MFMA-bound; two
-                                        # MFMA kernels sharing the chip LOSE throughput, an MFMA kernel beside an HBM-bound one gains):
-                                        #   0  released as soon as their dz exists (overlap whatever the chain runs next)
-                                        #   1  released after the layer's data-gradient conv, and the NEXT data-gradient conv waits for
-                                        #      them: they only ever run beside the HBM-bound kernels between two convs
-                                        #   2  like 1 but both GEMMs of a double_conv are released together after its second conv
-                                        #      (the long HBM phase: unpool / upsample backward + BatchNorm backward)
+        # The only tuning attributes (tools/ab_flag.py A/Bs them in one process).  Everything round 1 and 2 measured and lost -- the
+        # unfused BatchNorm-backward paths, relu(bn(z)) materialised for the weight gradient, the two-pass encoder skip backward,
+        # release schedules of the weight-gradient GEMMs -- is gone from the product (DESIGN.md section 4 keeps the findings,
+        # tools/experimental/ the code).
+        self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
+        self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._diag_skip_wgrad = False
-        self.wgrad_after_dgrad = False  # A/B: release a layer's weight-gradient GEMM only after its data-gradient conv was enqueued
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
         self._prof_seen = 0
         self.prof_filter = None    # only time launches of this kernel instantiation (an event pair is a ~150 us pipeline bubble)
@@ -226,13 +202,12 @@ class BiDateEngine:
         _lib.load()                # fail loudly now if the HIP extension is missing
 
     # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
-    def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg, act=False):
+    def conv_kernel_name(self, n, h, w, c0, c1, cout, ipg):
         """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to: asked from the library's own dispatcher."""
-        return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg,
-                                               1 if act else 0).decode()
+        return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg).decode()
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
-        name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg, act=fn == 'bdn_conv3x3_act') if self.prof is not None else None
+        name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
         if self.prof is None or (self.prof_filter is not None and name != self.prof_filter):
             call(fn, *args)
             return
@@ -322,21 +297,10 @@ class BiDateEngine:
             sp = ws.split_buf('a', n * hk * wk * 2 * (c0 + c1))
             call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
             in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
-        if training and in_mode == IN_BNRELU and self.fwd_writes_act and not self.x3 and \
-                _lib.load().bdn_conv3x3_act_supported(self.mdt, n, hk, wk, c0, L.cout, ipg):
-            act = ws.act.get(in0.data_ptr())
-            if act is None:
-                act = ws.act[in0.data_ptr()] = torch.empty_like(in0)
-            self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
-                             self.mdt, ptr(in0), c0, ptr(in_bn), ipg, ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats),
-                             ptr(act), n, hk, wk, L.cout, st, fn='bdn_conv3x3_act')
-            ws.act_valid.add(in0.data_ptr())
-        else:
-            ws.act_valid.discard(in0.data_ptr())
-            self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
-                             self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
-                             ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
-                             n, hk, wk, L.cout, st)
+        self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
+                         self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
+                         ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
+                         n, hk, wk, L.cout, st)
         bn = ws.bn[L.name]
         G = n // ipg
         if training:
@@ -450,7 +414,7 @@ class BiDateEngine:
         e = lambda *s: torch.empty(*s, dtype=td, device=dev)
         ready = on_ready or (lambda keys: None)
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if wgrad_stream and not (self.x3 and not self.x3_side_stream) else None
+        side = self._side_stream(dev) if wgrad_stream else None
 
         def bn_bwd(L, dA, ldA, n, ipg, fused_rows=0):
             """BatchNorm+ReLU backward of layer L.  fused_rows > 0: the kernel that produced dA already left the
@@ -480,17 +444,7 @@ class BiDateEngine:
                 call('bdn_conv3x3_wgrad_ex', BDN_BF16X3, ptr(sd), L.cout, ptr(sw), c0 + c1, None, 0, IN_PLAIN, None, ipg,
                      ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, 3, stp)
                 return
-            wk_ = self.wgrad_kernel
-            blk_ = self.wgrad_blocks_tail if (self.wgrad_blocks_tail and L.name in self.wgrad_tail_layers) else self.wgrad_blocks
-            if mode == IN_BNRELU and in0.data_ptr() in ws.act_valid:
-                in0, mode, in_bn = ws.act[in0.data_ptr()], IN_PLAIN, None      # written by this layer's forward (bdn_conv3x3_act)
-            if mode == IN_BNRELU and self.wgrad_dma and \
-                    lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, 0, ipg, IN_PLAIN, wg_flags(3, wk_, blk_)) in (WG_DMA, WG_DMA2):
-                # the DMA kernel's operands never pass through registers: write a = relu(bn(z)) once (instead of deriving it in
-                # each of the Cout/64 column-tile blocks of the GEMM) and hand the GEMM a plain tensor
-                act = sc['act'][:in0.numel()]
-                call('bdn_bnrelu', self.dt, ptr(in0), ptr(in_bn), ipg, ptr(act), n, hk, wk, c0, stp)
-                in0, mode, in_bn = act, IN_PLAIN, None
+            wk_, blk_ = self.wgrad_kernel, self.wgrad_blocks
             args = (self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
                     ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
             name = None
@@ -498,10 +452,6 @@ class BiDateEngine:
                 v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_, blk_))
                 if v == WG_ROLE:
                     name = f'wgrad7_kernel<{"true" if mode == IN_BNRELU else "false"}>'
-                elif v in (WG_DMA, WG_DMA2):
-                    name = f'wgrad6_kernel<{3 if v == WG_DMA else 2}>'
-                elif v == WG_PIPE:
-                    name = f'wgrad2_kernel<{"true" if mode == IN_BNRELU else "false"}>'
                 else:
                     small = wk <= 8 and hk <= 8 and ipg % 2 == 0
                     name = (f'wgrad_kernel<{"bf16" if self.precision == "bf16" else "f32"},8,{"8,2" if small else "16,1"},'
@@ -527,9 +477,6 @@ class BiDateEngine:
                 return
             hk, wk = ws.dims[L.level - 1]
             keys = [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias']
-            if side is not None and self.wgrad_sched:
-                pending.append((L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, keys))
-                return
             if side is None:
                 wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, st)
                 if zero_bias_grads:                  # feeds a BatchNorm: gradient is identically zero
@@ -545,39 +492,9 @@ class BiDateEngine:
                     grads[f'{L.conv}.bias'].zero_()
                 ready(keys)                          # a bucket all-reduce launched here is ordered behind this wgrad
 
-        pending, done = [], [None]
-
-        def release_wgrads():
-            """wgrad_sched 1/2: the chain has just enqueued a data-gradient conv and enters an HBM-bound phase: let the queued
-            weight-gradient GEMMs run beside it."""
-            if not pending:
-                return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                for (L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, keys) in pending:
-                    wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, side.cuda_stream)
-                    if zero_bias_grads:
-                        grads[f'{L.conv}.bias'].zero_()
-                    ready(keys)
-                d = torch.cuda.Event()
-                d.record(side)
-            done[0] = d
-            pending.clear()
-
         def dgrad(L, dz, n, ipg, prev=None):
             """Data gradient of layer L's conv.  prev = the layer whose relu(bn(z)) is this conv's input: its
             BatchNorm-backward partial sums are then produced by the epilogue (returns rows per statistic group)."""
-            out = dgrad_(L, dz, n, ipg, prev)
-            if self.wgrad_sched == 1 or (self.wgrad_sched == 2 and L.name.endswith('a')):
-                release_wgrads()
-            return out
-
-        def dgrad_(L, dz, n, ipg, prev=None):
-            if done[0] is not None:                  # the previous phase's weight-gradient GEMMs must be off the matrix cores
-                main.wait_event(done[0])
-                done[0] = None
             hk, wk = ws.dims[L.level - 1]
             _, wd = self._weights(L, P, True)
             out = e(n, hk, wk, L.cin)
@@ -585,30 +502,28 @@ class BiDateEngine:
                 sp = ws.split_buf('d', n * hk * wk * 2 * L.cout)
                 call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sp), n, hk, wk, st)
                 dz = sp
-            if prev is None or not self.fuse_bn_bwd_stats:
+            if prev is None:
                 self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
                                  self.mdt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
                                  ptr(wd), None, ptr(out), None, n, hk, wk, L.cin, st)
-                return out if prev is None else (out, 0)
+                return out
             self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
                              self.mdt, ptr(dz), L.cout, ptr(wd), ptr(out), ptr(ws.z[prev.name]), ptr(ws.bn[prev.name]),
                              ipg, ptr(ws.stats), n, hk, wk, L.cin, st, fn='bdn_conv3x3_dgrad_bs')
             rows = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // (n // ipg)
             return out, rows
 
-        # ---- classifier
+        # ---- classifier: its data gradient is never stored -- bdn_outc_bwd leaves the BatchNorm-backward partial sums of d4b, and
+        # d4b's BatchNorm backward recomputes dA = round(sum_k dlogits[k] w[k][c]) (bit-identical dz, 134 MB less footprint)
         L4b = by['d4b']
-        fuse = self.fuse_bn_bwd_stats
-        head_fused = fuse and self.fuse_head_bwd     # the classifier's data gradient is recomputed by d4b's BatchNorm backward, never stored
-        dA = None if head_fused else e(B, H, W, L4b.cout)
         call('bdn_outc_bwd', self.dt, ptr(dlogits), ptr(ws.z['d4b']), ptr(ws.bn['d4b']), ptr(P['outc.conv.weight']),
-             ptr(dA), ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), ptr(ws.stats) if fuse else None,
+             None, ptr(grads['outc.conv.weight']), ptr(grads['outc.conv.bias']), ptr(ws.stats),
              ptr(ws.outc_ws(self)), B, H, W, L4b.cout, self.n_classes, st)
-        rows_head = _lib.load().bdn_outc_bwd_rows(self.dt, B, H, W, L4b.cout) if fuse else 0
+        rows_head = _lib.load().bdn_outc_bwd_rows(self.dt, B, H, W, L4b.cout)
         ready(['outc.conv.weight', 'outc.conv.bias'])
         # ---- decoder
-        dA_ptr, ldA = ptr(dA), L4b.cout
-        keep = [dA]
+        dA_ptr, ldA = None, 0
+        keep = []
         dcat = {}
         dF5 = None
         for j in range(4, 0, -1):
@@ -618,26 +533,19 @@ class BiDateEngine:
             La, Lb = by[f'd{j}a'], by[f'd{j}b']
             ck = ENC_CH[k - 1]
             cprev = La.cin - ck
-            late = self.wgrad_after_dgrad
-            if j == 4 and head_fused:
+            if j == 4:
                 dzb = e(B, hk, wk, Lb.cout)
                 call('bdn_bn_bwd_finalize', ptr(ws.bn[Lb.name]), 1, Lb.cout, ptr(ws.stats), rows_head, 1, ptr(sc['sums']),
                      ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
                 call('bdn_outc_bn_bwd_apply', self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
                      ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dzb), B, hk, wk, Lb.cout, self.n_classes, st)
             else:
-                dzb = bn_bwd(Lb, dA_ptr, ldA, B, B, fused_rows=rows_head if j == 4 else 0)
-            if not late:
-                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
+                dzb = bn_bwd(Lb, dA_ptr, ldA, B, B)         # dA came from upsample2x_bwd: the one producer without fused sums
+            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
-            if late:
-                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
-            if not late:
-                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
+            wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             dc = dgrad(La, dza, B, B)                       # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
-            if late:
-                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             dcat[k] = dc
             dprev = e(B, hs, wsrc, cprev)
             call('bdn_upsample2x_bwd', self.dt, dc.data_ptr() + ck * es, La.cin, ptr(dprev), B, hs, wsrc, hk, wk, cprev, st)
@@ -648,7 +556,6 @@ class BiDateEngine:
                 dF5 = dprev
         # ---- encoder (both dates at once)
         dP = None
-        late = self.wgrad_after_dgrad
         for k in range(5, 0, -1):
             hk, wk = ws.dims[k - 1]
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
@@ -657,32 +564,14 @@ class BiDateEngine:
                 dF_ptr, ldF = ptr(dF5), ck
             else:
                 dF_ptr, ldF = ptr(dcat[k]), dcat[k].shape[3]
-            fuse = self.fuse_bn_bwd_stats
-            rows_b = _lib.load().bdn_enc_skip_bwd_rows(self.dt, B, hk, wk, ck) if fuse else 0
-            if fuse and self.enc_two_pass:
-                # dA of the skip / unpool backward is never written: one pass for the BatchNorm-backward sums, one that
-                # recomputes dA and writes dz (the skip gradient, the pooled gradient and z are read twice instead of dA being
-                # written once and read once: 22 % fewer bytes)
-                dAb = None
-                dzb = e(2 * B, hk, wk, ck)
-                call('bdn_enc_skip_bwd_ex', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
-                     ptr(dP), None, ptr(ws.stats), None, 1, B, hk, wk, ck, st)
-                call('bdn_bn_bwd_finalize', ptr(ws.bn[Lb.name]), 2, ck, ptr(ws.stats), rows_b, 1, ptr(sc['sums']),
-                     ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
-                call('bdn_enc_skip_bwd_ex', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
-                     ptr(dP), ptr(dzb), None, ptr(sc['sums']), 2, B, hk, wk, ck, st)
-            else:
-                dAb = e(2 * B, hk, wk, ck)
-                call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
-                     ptr(dP), ptr(dAb), ptr(ws.stats) if fuse else None, B, hk, wk, ck, st)
-                dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
-            if not late:
-                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
+            rows_b = _lib.load().bdn_enc_skip_bwd_rows(self.dt, B, hk, wk, ck)
+            dAb = e(2 * B, hk, wk, ck)
+            call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
+                 ptr(dP), ptr(dAb), ptr(ws.stats), B, hk, wk, ck, st)
+            dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
+            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
             dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
-            if late:
-                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
-            if k == 1 and rows and self.fuse_first_wgrad and \
-                    _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.mdt, 2 * B, hk, wk, La.cout, La.cin, B):
+            if k == 1 and _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.mdt, 2 * B, hk, wk, La.cout, La.cin, B):
                 # the first conv has no data gradient: its dz has one reader, so the BatchNorm backward is applied inside
                 # that weight-gradient GEMM's staging and the largest tensor of the step is never written (on the main
                 # stream: nothing of the chain is left to run, the side stream is still busy with e1b's GEMM)
@@ -701,7 +590,6 @@ class BiDateEngine:
                         call('bdn_conv3x3_wgrad_bnbwd', *wargs)
                 if zero_bias_grads:
                     grads[f'{La.conv}.bias'].zero_()
-                release_wgrads()
                 if side is not None:
                     # this ready() may launch the LAST bucket's all-reduce, ordered behind the current (main) stream only;
                     # the bucket also holds e1b / e2a weight gradients whose GEMM + reduction are still queued on the side
@@ -713,13 +601,9 @@ class BiDateEngine:
                 continue
             dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
             src = ws.x0 if k == 1 else ws.pool[k]
-            if not late:
-                wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
+            wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
             keep += [dAb, dzb, dAa, dza, dP]
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
-            if late:
-                wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
-        release_wgrads()
         if side is not None:
             main.wait_stream(side)                   # every weight gradient is complete before the caller's next kernel
         return grads

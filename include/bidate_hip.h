@@ -66,18 +66,9 @@ int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 const void* w, const float* bias, void* out, float* stats_partial,
                 int N, int H, int W, int Cout, void* stream);
 int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group);
-/* bdn_conv3x3 with a BatchNorm+ReLU input (in_mode BDN_IN_BNRELU, one source) that ALSO writes the post-activation tensor
- * it stages, act_out [N,H,W,C0] = relu(in0*scale + shift) in the storage type (models/unet_parts.py:14-15) -- the operand of
- * this layer's weight gradient, materialised at the cost of the stores only.  bf16, the large shape classes only
- * (bdn_conv3x3_act_supported); BDN_E_SHAPE otherwise. */
-int bdn_conv3x3_act_supported(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group);   /* 1: bdn_conv3x3_act runs this shape */
-int bdn_conv3x3_act(int dtype, const void* in0, int C0, const float* in_bn, int imgs_per_group,
-                    const void* w, const float* bias, void* out, float* stats_partial, void* act_out,
-                    int N, int H, int W, int Cout, void* stream);
-/* Name of the kernel instantiation bdn_conv3x3 (act = 0) / bdn_conv3x3_act (act = 1) runs for a shape, e.g.
- * "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false>" (the rocprofv3 name with `unsigned short` spelled bf16);
- * "" for an unsupported shape.  Thread-local buffer. */
-const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group, int act);
+/* Name of the kernel instantiation bdn_conv3x3 runs for a shape, e.g. "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false>"
+ * (the rocprofv3 name with `unsigned short` spelled bf16); "" for an unsupported shape.  Thread-local buffer. */
+const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group);
 
 /* Data gradient of nn.Conv2d(ci,co,3,padding=1) (autograd of models/unet_parts.py:13,16) with the BatchNorm-backward
  * statistics of the PRODUCING layer fused into the epilogue: dz [N,H,W,C0] x rotated filter image w_dgrad ->
@@ -130,16 +121,15 @@ int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
 /* The same with a per-call `flags` word (there is no process-wide tuning state):
  *   bits 0-1   phases: bit 0 = split-K GEMM into `partial`, bit 1 = fixed-order reduction into dw_oihw (a profiler can
  *              bracket the GEMM alone by issuing the phases apart);
- *   bits 8-11  kernel override (0 = the library's choice): BDN_WG_SIMPLE, BDN_WG_PIPE, BDN_WG_DMA, BDN_WG_DMA2 -- honoured where the
- *              shape class allows it, ignored otherwise (ask bdn_conv3x3_wgrad_variant what a call will run);
+ *   bits 8-11  kernel override (0 = the library's choice): BDN_WG_SIMPLE forces the one-chunk-at-a-time kernel
+ *              (bdn_conv3x3_wgrad_variant says what a call will run: BDN_WG_SIMPLE or BDN_WG_ROLE);
  *   bits 16-28 target number of blocks of the GEMM (0 = default 128: half the CUs, the GEMM shares the chip with the dz chain).
  * With non-default flags `partial` must hold bdn_wgrad_workspace_bytes_ex(same arguments).  Results are deterministic
  * for fixed flags; different plans differ only in the summation order of the partial tiles. */
 #define BDN_WG_SIMPLE 1      /* one-chunk-at-a-time kernel (any dtype, first layer, 8x8 maps) */
-#define BDN_WG_PIPE   2      /* software-pipelined bf16 kernel, operands staged through registers (BatchNorm+ReLU on load) */
-#define BDN_WG_DMA    3      /* bf16 kernel whose operands go HBM -> LDS by buffer_load ... lds (plain inputs only), 3 LDS buffers */
-#define BDN_WG_DMA2   4      /* the same with 2 LDS buffers (80 KB): leaves room for a convolution block on the same CU */
-#define BDN_WG_ROLE   5      /* role-split bf16 kernel: four MFMA waves + four staging waves (BatchNorm+ReLU on load or plain), 3 LDS buffers */
+#define BDN_WG_ROLE   5      /* role-split bf16 kernel (64-channel tiles, 8x16 spatial tiles): four MFMA waves fed by four staging waves --
+                                dz tile by LDS-DMA, halo patch by LDS-DMA (plain) or through registers with BatchNorm+ReLU on load; 3 LDS buffers.
+                                (2-4 were the round-1/2 kernels it replaced: tools/experimental/wgrad_v2_v6.hip.inc) */
 #define BDN_WG_FLAGS(phases, kernel, blocks) ((phases) | ((kernel) << 8) | ((blocks) << 16))
 size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
                                     int in_mode, int flags);
@@ -202,8 +192,7 @@ int bdn_bn_bwd_finalize(const float* bn, int G, int C, const float* partial, int
                         float* sums, float* dgamma, float* dbeta, void* scratch, void* stream);
 
 /* a = relu(z*scale + shift) written out (nn.BatchNorm2d + nn.ReLU, models/unet_parts.py:14-15): z, out [N,H,W,C]; bn [G][4][C].
- * Rounded exactly like the on-load application inside bdn_conv3x3 / bdn_conv3x3_wgrad, whose BDN_WG_DMA kernel needs a
- * plain operand. */
+ * Rounded exactly like the on-load application inside bdn_conv3x3 / bdn_conv3x3_wgrad; bdn_conv3d_wgrad takes plain operands only. */
 int bdn_bnrelu(int dtype, const void* z, const float* bn, int imgs_per_group, void* out,
                int N, int H, int W, int C, void* stream);
 /* ---- nn.MaxPool2d(2) on relu(bn(z)): models/unet_parts.py:40 (floor mode) ---- */
@@ -237,12 +226,6 @@ int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const fl
 /* bs_partial: NULL, or f32 [2][bdn_enc_skip_bwd_rows(dtype,B,H,W,C)][2][C] receiving the BatchNorm-backward partial
  * sums of the layer (per block: sum g, sum g*z; date 1 rows then date 2 rows) -> bdn_bn_bwd_apply(raw_moment = 1). */
 int bdn_enc_skip_bwd_rows(int dtype, int B, int H, int W, int C);
-/* The same in two passes that never write dA: mode 1 = the partial sums only (out unused), then bdn_bn_bwd_finalize(G = 2,
- * raw_moment = 1) turns them into `sums` [2][2][C], then mode 2 recomputes dA and writes out = dz = BatchNorm+ReLU backward
- * of it (bit for bit what mode 0 + bdn_bn_bwd_apply give; 22 % fewer HBM bytes).  mode 0 = bdn_enc_skip_bwd. */
-int bdn_enc_skip_bwd_ex(int dtype, const void* dF, int ldF, const void* z, const float* bn,
-                        const void* dP, void* out, float* bs_partial, const float* sums, int mode,
-                        int B, int H, int W, int C, void* stream);
 
 /* ---- outconv: nn.Conv2d(64, n_classes, 1), models/unet_parts.py:86 ----
  * z: [B,H,W,C] raw output of up4's second conv, bn: [1][4][C]; w: [ncls][C] f32, b: [ncls];

@@ -42,7 +42,7 @@ ts = TrainStep(model, lr=lr, n_buckets=3)
 assert ts.world == world
 eng = model.engine()
 if precision == 'bf16' and c == 13:
-    assert eng.fuse_first_wgrad and _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(eng.dt, 2 * b, s, s, 64, 16, b), \
+    assert _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(eng.dt, 2 * b, s, s, 64, 16, b), \
         'this case must exercise the fused first-layer weight gradient'
     last = ts.bucketer.buckets[-1][2]
     assert any(k.startswith('inc.conv.conv.3') for k in last) or any(k.startswith('down1') for k in last), last

@@ -249,46 +249,6 @@ def test_bnrelu_materialised(prec, shape):
         _lib.call('bdn_bnrelu', dt, z_d.data_ptr(), bn_d.data_ptr(), ipg, out.data_ptr(), N, H, W, C + 1, st())
 
 
-@pytest.mark.parametrize('case', [(4, 32, 32, 64, 64, 2), (2, 37, 50, 64, 64, 1), (16, 64, 64, 128, 128, 8), (32, 45, 64, 256, 256, 16),
-                                  (32, 40, 60, 64, 128, 16)])
-def test_conv3x3_act_writes_the_staged_activation(case):
-    """bdn_conv3x3_act == bdn_conv3x3 (same output and statistics, bit for bit) + the relu(bn(in0)) tensor it staged, equal to
-    bdn_bnrelu's (the operand of the layer's weight gradient, models/unet_parts.py:14-16); every pixel written exactly once,
-    ragged tiles included."""
-    N, H, W, Cin, Cout, ipg = case
-    lib = _lib.load()
-    dt, td = DT['bf16']
-    assert lib.bdn_conv3x3_act_supported(dt, N, H, W, Cin, Cout, ipg) == 1
-    x = to_nhwc('bf16', rnd('bf16', _rand((N, Cin, H, W), 401)))
-    bn_d = dev(bn_table(N // ipg, Cin, 402))
-    w = rnd('bf16', _rand((Cout, Cin, 3, 3), 403) * 0.1)
-    wf, _ = pack_w('bf16', w, Cin)
-    bias = dev(_rand((Cout,), 404))
-    nt = lib.bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
-    outs = []
-    for act in (False, True):
-        out = torch.full((N, H, W, Cout), float('nan'), dtype=td, device='cuda')
-        stats = torch.full((nt, 2, Cout), float('nan'), device='cuda')
-        a = torch.full((N, H, W, Cin), float('nan'), dtype=td, device='cuda')
-        if act:
-            _lib.call('bdn_conv3x3_act', dt, x.data_ptr(), Cin, bn_d.data_ptr(), ipg, wf.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                      stats.data_ptr(), a.data_ptr(), N, H, W, Cout, st())
-        else:
-            _lib.call('bdn_conv3x3', dt, x.data_ptr(), Cin, None, 0, IN_BNRELU, bn_d.data_ptr(), ipg, wf.data_ptr(), bias.data_ptr(),
-                      out.data_ptr(), stats.data_ptr(), N, H, W, Cout, st())
-            _lib.call('bdn_bnrelu', dt, x.data_ptr(), bn_d.data_ptr(), ipg, a.data_ptr(), N, H, W, Cin, st())
-        torch.cuda.synchronize()
-        outs.append((out.cpu(), stats.cpu(), a.cpu()))
-    for got, want, what in zip(outs[1], outs[0], ('output', 'statistics', 'activation')):
-        assert torch.isfinite(got.float()).all(), what
-        assert torch.equal(got, want), what
-    assert lib.bdn_conv3x3_act_supported(dt, N, 8, 8, Cin, Cout, ipg) == 0        # 8x8 maps: no activation-writing variant
-    assert lib.bdn_conv3x3_act_supported(DT['fp32'][0], N, H, W, Cin, Cout, ipg) == 0
-    with pytest.raises(RuntimeError):
-        _lib.call('bdn_conv3x3_act', dt, x.data_ptr(), Cin, bn_d.data_ptr(), ipg, wf.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                  stats.data_ptr(), a.data_ptr(), N, 8, 8, Cout, st())
-
-
 @pytest.mark.parametrize('prec', PRECS)
 def test_fuse_product(prec):
     B, H, W, C = 3, 10, 12, 64
@@ -382,26 +342,6 @@ def test_enc_skip_bwd(prec, case):
     # multiplied by the producer's own ReLU mask [a > 0] in the very next step (bn_bwd), so compare there.
     live = (a.detach() > 0).float()
     assert_close('enc_skip_bwd', from_nhwc(out) * live, ref * live, 1e-6 if prec == 'fp32' else 8e-3)
-    # two passes that never write dA (mode 1: sums only, mode 2: recompute + BatchNorm backward) == mode 0 + bdn_bn_bwd_apply, bit for bit
-    lib = _lib.load()
-    sums = torch.empty(2, 2, C, device='cuda')
-    dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-    scratch = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device='cuda')
-    dz_ref = torch.full((2 * B, H, W, C), float('nan'), dtype=td, device='cuda')
-    _lib.call('bdn_bn_bwd_apply', dt, out.data_ptr(), C, z_d.data_ptr(), bn_d.data_ptr(), B, 2 * B, H, W, C, part.data_ptr(), rows, 1,
-              sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz_ref.data_ptr(), scratch.data_ptr(), st())
-    part2 = torch.full((2, rows, 2, C), float('nan'), device='cuda')
-    _lib.call('bdn_enc_skip_bwd_ex', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
-              dP_d.data_ptr() if pooled else None, None, part2.data_ptr(), None, 1, B, H, W, C, st())
-    sums2, dg2, db2 = torch.empty(2, 2, C, device='cuda'), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-    _lib.call('bdn_bn_bwd_finalize', bn_d.data_ptr(), 2, C, part2.data_ptr(), rows, 1, sums2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
-              scratch.data_ptr(), st())
-    dz = torch.full((2 * B, H, W, C), float('nan'), dtype=td, device='cuda')
-    _lib.call('bdn_enc_skip_bwd_ex', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
-              dP_d.data_ptr() if pooled else None, dz.data_ptr(), None, sums2.data_ptr(), 2, B, H, W, C, st())
-    torch.cuda.synchronize()
-    assert torch.equal(part2, part) and torch.equal(sums2, sums) and torch.equal(dg2, dg) and torch.equal(db2, db)
-    assert torch.isfinite(dz.float()).all() and torch.equal(dz, dz_ref)
 
 
 # ------------------------------------------------------------------ classifier
@@ -749,7 +689,7 @@ def test_wgrad_phases_variant_and_per_call_flags():
     """bdn_conv3x3_wgrad_ex(phases 1 then 2) == bdn_conv3x3_wgrad; the per-call grid-size field changes the workspace, not the
     result beyond the summation order of the partial tiles; bdn_conv3x3_wgrad_variant names the kernel family; there is no
     process-wide tuning state (the sizing query is a pure function of its arguments)."""
-    from fabric_amd._lib import WG_PIPE, WG_SIMPLE, wg_flags
+    from fabric_amd._lib import WG_SIMPLE, wg_flags
     lib = _lib.load()
     N, H, W, Cout, C0, ipg = 16, 32, 32, 128, 64, 8
     dt, td = DT['bf16']
@@ -793,10 +733,11 @@ def test_wgrad_phases_variant_and_per_call_flags():
 
 @pytest.mark.parametrize('mode', ['bnrelu', 'plain', 'plain2'])
 def test_wgrad_kernel_variants_agree(mode):
-    """Every weight-gradient kernel a shape may run gives the same dW up to the summation order of the partial tiles
-    (ragged map, two statistic groups / two concatenated sources); with the same split plan the pipelined kernels are
-    bit-identical to each other."""
-    from fabric_amd._lib import WG_DMA, WG_PIPE, WG_ROLE, WG_SIMPLE, wg_flags
+    """Both weight-gradient kernels a shape may run give the same dW up to the summation order of the partial tiles
+    (ragged map, two statistic groups / two concatenated sources).  The role-split kernel stages the patch through its
+    producer waves' registers with BatchNorm+ReLU ('bnrelu') or by LDS-DMA ('plain'): a plain operand that already holds
+    relu(bn(z)) (bdn_bnrelu) must give the BatchNorm-on-load result bit for bit."""
+    from fabric_amd._lib import WG_ROLE, WG_SIMPLE, wg_flags
     lib = _lib.load()
     N, H, W, Cout, ipg = 6, 37, 50, 128, 3
     dt, td = DT['bf16']
@@ -811,7 +752,7 @@ def test_wgrad_kernel_variants_agree(mode):
         x1 = to_nhwc('bf16', rnd('bf16', _rand((N, C1, H, W), 198))) if C1 else None
         bn_d, in_mode = None, IN_PLAIN
     out, ran = {}, {}
-    for v in (WG_SIMPLE, WG_PIPE, WG_DMA, WG_ROLE):
+    for v in (WG_SIMPLE, WG_ROLE):
         fl = wg_flags(3, v, 0)
         ran[v] = lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, C1, ipg, in_mode, fl)
         part = torch.empty(lib.bdn_wgrad_workspace_bytes_ex(dt, N, H, W, Cout, C0, C1, ipg, in_mode, fl) // 4, device='cuda')
@@ -821,13 +762,18 @@ def test_wgrad_kernel_variants_agree(mode):
         torch.cuda.synchronize()
         out[v] = dw.cpu()
         assert torch.isfinite(out[v]).all()
-    assert ran[WG_SIMPLE] == WG_SIMPLE and ran[WG_PIPE] == WG_PIPE
-    assert_close('pipelined vs simple', out[WG_PIPE], out[WG_SIMPLE], 2e-6)
-    assert ran[WG_ROLE] == WG_ROLE and torch.equal(out[WG_ROLE], out[WG_PIPE])    # role-split kernel: BatchNorm on load or plain
-    if ran[WG_DMA] == WG_DMA:
-        assert torch.equal(out[WG_DMA], out[WG_PIPE])
-    else:
-        assert mode == 'bnrelu'                              # BatchNorm on load needs the register-staged kernel
+    assert ran[WG_SIMPLE] == WG_SIMPLE and ran[WG_ROLE] == WG_ROLE
+    assert_close('role-split vs simple', out[WG_ROLE], out[WG_SIMPLE], 2e-6)
+    if mode == 'bnrelu':                                     # register path (BatchNorm on load) == LDS-DMA path on the materialised operand
+        act = torch.empty_like(x0)
+        _lib.call('bdn_bnrelu', dt, x0.data_ptr(), bn_d.data_ptr(), ipg, act.data_ptr(), N, H, W, C0, st())
+        fl = wg_flags(3, WG_ROLE, 0)
+        part = torch.empty(lib.bdn_wgrad_workspace_bytes_ex(dt, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, fl) // 4, device='cuda')
+        dw = torch.full((Cout, C0, 3, 3), float('nan'), device='cuda')
+        _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, act.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg,
+                  part.data_ptr(), dw.data_ptr(), C0, N, H, W, fl, st())
+        torch.cuda.synchronize()
+        assert torch.equal(dw.cpu(), out[WG_ROLE])
 
 # ------------------------------------------------------------------ bf16x3: float32 tensors, bf16 hi/lo split GEMM operands
 def _split_ref(t_nchw):

@@ -123,64 +123,6 @@ def test_train_step_matches_reference(golden_dir, name, prec):
     assert d2.max() <= (0.25 if prec == 'bf16' else 1e-3)
 
 
-@pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
-def test_head_fusion_switch_leaves_every_gradient_unchanged(golden_dir, name):
-    """engine.fuse_head_bwd: d4b's BatchNorm backward recomputes the classifier's data gradient instead of reading it back --
-    same numbers, bit for bit (no float atomics anywhere on the training path)."""
-    g, c, x1, x2, lbl = _load(golden_dir, name)
-    grads = {}
-    for fused in (False, True):
-        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
-        model.engine().fuse_head_bwd = fused
-        _tversky_torch(model(x1, x2), lbl).backward()
-        torch.cuda.synchronize()
-        grads[fused] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
-    for k in grads[True]:
-        a, b = grads[True][k], grads[False][k]
-        assert torch.equal(a, b), k
-
-
-@pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
-def test_first_layer_fused_weight_gradient_equals_two_kernel_path(golden_dir, name):
-    """engine.fuse_first_wgrad (bf16): BatchNorm backward applied inside the first conv's weight-gradient GEMM.  Every other
-    conv / BatchNorm gradient is produced by the same kernels (bit-equal); inc's conv weight differs only by summation order."""
-    g, c, x1, x2, lbl = _load(golden_dir, name)
-    grads = {}
-    for fused in (False, True):
-        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
-        model.engine().fuse_first_wgrad = fused
-        loss = _tversky_torch(model(x1, x2), lbl)
-        loss.backward()
-        torch.cuda.synchronize()
-        grads[fused] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
-    for k in grads[True]:
-        a, b = grads[True][k], grads[False][k]
-        if k == 'inc.conv.conv.0.weight':
-            assert (a - b).abs().max() <= 2e-6 * b.abs().max(), k
-            assert not torch.equal(a, torch.zeros_like(a))
-        else:
-            assert torch.equal(a, b), k
-
-
-@pytest.mark.parametrize('name', ['g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
-def test_dma_weight_gradient_switch_leaves_every_gradient_unchanged(golden_dir, name):
-    """engine.fwd_writes_act / engine.wgrad_dma (bf16): relu(bn(z)) materialised (by the forward conv that stages it, or by a
-    separate pass) + the LDS-DMA weight-gradient kernel, instead of BatchNorm on load inside the register-staged kernel -- same
-    operands, same split plan, same accumulation order: bit-equal gradients."""
-    g, c, x1, x2, lbl = _load(golden_dir, name)
-    grads = {}
-    for dma in (False, True, 'fwd'):
-        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
-        model.engine().wgrad_dma = dma is True                  # True: separate bdn_bnrelu pass on the weight-gradient stream
-        model.engine().fwd_writes_act = dma == 'fwd'            # 'fwd': the forward conv writes the activation it stages (default)
-        _tversky_torch(model(x1, x2), lbl).backward()
-        torch.cuda.synchronize()
-        grads[dma] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
-    for k in grads[True]:
-        assert torch.equal(grads[True][k], grads[False][k]), k
-        assert torch.equal(grads['fwd'][k], grads[False][k]), k
-
-
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, prec):
     """Plain autograd usage the reference supports: two micro-batches (and an eval forward in between) before one backward.

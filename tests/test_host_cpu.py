@@ -44,13 +44,11 @@ def test_argument_validation_needs_no_gpu():
     with pytest.raises(RuntimeError, match='4 GB'):       # 32-bit byte offsets inside the kernel: 4096 x 128 x 128 x 64 bf16 = 8 GB
         _lib.call('bdn_conv3x3', 1, 1, 64, None, 0, 0, None, 1, 1, None, 1, None, 4096, 128, 128, 64, None)
     # round-2 entry points: plans are pure functions of their arguments, errors come before anything touches a device
-    from fabric_amd._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_DMA, WG_PIPE, WG_ROLE, WG_SIMPLE, wg_flags
+    from fabric_amd._lib import BDN_BF16, BDN_BF16X3, BDN_F32, IN_BNRELU, IN_PLAIN, WG_ROLE, WG_SIMPLE, wg_flags
     var = lib.bdn_conv3x3_wgrad_variant
     assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) == WG_ROLE       # role-split kernel, plain operands by LDS-DMA
     assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_BNRELU, 0) == WG_ROLE      # ... BatchNorm+ReLU on load by its producer waves
-    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, wg_flags(kernel=WG_DMA)) == WG_DMA
-    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_BNRELU, wg_flags(kernel=WG_DMA)) == WG_ROLE   # the LDS-DMA kernel needs a plain operand
-    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, wg_flags(kernel=WG_PIPE)) == WG_PIPE
+    assert var(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, wg_flags(kernel=WG_SIMPLE)) == WG_SIMPLE
     assert var(BDN_F32, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) == WG_SIMPLE
     assert var(BDN_BF16, 128, 8, 8, 512, 512, 0, 64, IN_PLAIN, 0) == WG_SIMPLE
     wsb = lib.bdn_wgrad_workspace_bytes_ex
@@ -59,12 +57,9 @@ def test_argument_validation_needs_no_gpu():
     assert wsb(BDN_BF16, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, wg_flags(0, 0, 256)) == 2 * half
     assert wsb(BDN_BF16X3, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) > half             # doubled operands + the quadrant tile
     assert lib.bdn_wgrad_workspace_bytes(128, 64, 64, 128, 128, 64) >= wsb(BDN_BF16X3, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0)
-    assert lib.bdn_conv3x3_act_supported(BDN_BF16, 128, 128, 128, 64, 64, 64) == 1
-    assert lib.bdn_conv3x3_act_supported(BDN_BF16, 128, 8, 8, 512, 512, 64) == 0
     assert lib.bdn_conv3d_num_mtiles(8, 5, 128, 128) == 8 * 5 * 16 * 8
-    assert lib.bdn_conv3x3_variant(BDN_BF16, 128, 64, 64, 128, 0, 128, 64, 0) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false>'
-    assert lib.bdn_conv3x3_variant(BDN_BF16, 128, 64, 64, 128, 0, 128, 64, 1) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,true,false>'
-    assert lib.bdn_conv3x3_variant(BDN_BF16X3, 128, 64, 64, 128, 0, 128, 64, 0).endswith(b'float,false,false>')
+    assert lib.bdn_conv3x3_variant(BDN_BF16, 128, 64, 64, 128, 0, 128, 64) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false>'
+    assert lib.bdn_conv3x3_variant(BDN_BF16X3, 128, 64, 64, 128, 0, 128, 64).endswith(b'float,false>')
     for name, args, msg in (
             ('bdn_conv3d', (BDN_BF16, None, 64, 0, None, 1, None, None, None, None, 1, 1, 8, 8, 64, None), 'null pointer'),
             ('bdn_conv3d', (BDN_BF16X3, 1, 64, 0, None, 1, 1, None, 1, None, 1, 1, 8, 8, 64, None), 'bad dtype'),
@@ -73,10 +68,6 @@ def test_argument_validation_needs_no_gpu():
             ('bdn_split_pack', (1, 12, None, 0, 0, None, 1, 1, 1, 8, 8, None), 'bad shape'),
             ('bdn_split_pack', (1, 16, None, 0, 1, None, 1, 1, 1, 8, 8, None), 'needs in_bn'),
             ('bdn_bnrelu', (BDN_BF16, 1, 1, 1, 1, 2, 8, 8, 24, None), 'bad shape'),
-            ('bdn_conv3x3_act', (BDN_BF16, 1, 64, None, 1, 1, None, 1, None, 1, 2, 8, 8, 64, None), 'null pointer'),
-            ('bdn_conv3x3_act', (BDN_F32, 1, 64, 1, 1, 1, None, 1, None, 1, 2, 32, 32, 64, None), 'no activation-writing variant'),
-            ('bdn_enc_skip_bwd_ex', (BDN_BF16, 1, 64, 1, 1, None, None, None, None, 2, 1, 8, 8, 64, None), 'null pointer for mode 2'),
-            ('bdn_enc_skip_bwd_ex', (BDN_BF16, 1, 64, 1, 1, None, 1, None, None, 7, 1, 8, 8, 64, None), 'bad mode'),
             ('bdn_conv3x3_wgrad_ex', (BDN_BF16X3, 1, 64, 1, 64, 1, 64, 0, None, 1, 1, 1, 64, 2, 8, 8, 3, None), 'one split-packed'),
             ('bdn_conv3x3_wgrad_ex', (BDN_BF16, 1, 64, 1, 64, None, 0, 0, None, 1, 1, 1, 64, 2, 8, 8, 0, None), 'phases')):
         with pytest.raises(RuntimeError, match=msg):

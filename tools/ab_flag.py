@@ -12,7 +12,7 @@ torch.manual_seed(0)
 model = BiDateNet(13, 2, precision='bf16').cuda().train()
 step = TrainStep(model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9)
 typ = type(getattr(model.engine(), name))
-for kv in os.environ.get('AB_SET', '').split(','):          # other engine attributes held fixed during the A/B:  AB_SET=wgrad_dma=0,wgrad_kernel=2
+for kv in os.environ.get('AB_SET', '').split(','):          # other engine attributes held fixed during the A/B:  AB_SET=wgrad_blocks=192
     if kv:
         k, v = kv.split('=')
         setattr(model.engine(), k, type(getattr(model.engine(), k))(int(v)))

@@ -1,6 +1,6 @@
 """A/B of engine switches inside ONE process (boxes differ by +-10 %, so variants must share a run):
 alternates blocks of training steps with each setting and prints the median ms/step per setting.
-usage: python tools/ab_step.py attr=val0,val1 [blocks] [steps_per_block]      e.g. fuse_bn_bwd_stats=0,1"""
+usage: python tools/ab_step.py attr=val0,val1 [blocks] [steps_per_block]      e.g. wgrad_blocks=0,192"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -81,25 +81,15 @@ if what in ('wgrad', 'all'):
         dw = torch.empty(L.cout, L.cin_real, 3, 3, device='cuda')
         fl = 2.0 * n * h * w * L.cout * 9 * (c0 + c1)
         line = f'{L.name:5s} wgrad N={n:3d} {h:3d}x{w:3d} Cin={c0 + c1:4d} Cout={L.cout:4d} '
-        # every kernel the shape may run: register-staged pipeline (BatchNorm on load for the b layers), and the LDS-DMA
-        # kernel on a plain operand (+ the one-off bdn_bnrelu pass that materialises it for the b layers)
-        for kern, kname in ((_lib.WG_PIPE, 'pipe'), (_lib.WG_DMA, 'dma'), (_lib.WG_ROLE, 'role')):
-            m = mode if kern != _lib.WG_DMA else 0
-            flg = _lib.wg_flags(1, kern, 0)
-            ran = lib.bdn_conv3x3_wgrad_variant(dt, n, h, w, L.cout, c0, c1, ipg, m, flg)
-            fn = lambda: _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), L.cout, a0.data_ptr(), c0, a1.data_ptr() if c1 else None, c1,
-                                   m, bn.data_ptr(), ipg, part.data_ptr(), dw.data_ptr(), L.cin_real, n, h, w, flg, st)
-            t = timeit(fn)
-            line += f' | {kname}->{ran} {t * 1e6:7.1f} us {fl / t / 1e12:6.1f} TF/s'
-            if kern == _lib.WG_DMA or lib.bdn_conv3x3_wgrad_variant(dt, n, h, w, L.cout, c0, c1, ipg, 0, 0) != _lib.WG_DMA:
-                wt_t += t; wt_f += fl
-        if mode == 1 and c0 % 16 == 0:
-            act = torch.empty_like(a0)
-            t = timeit(lambda: _lib.call('bdn_bnrelu', dt, a0.data_ptr(), bn.data_ptr(), ipg, act.data_ptr(), n, h, w, c0, st))
-            line += f' | bnrelu {t * 1e6:6.1f} us'
-            wt_t += t
+        # the kernel the training step runs for the shape (role-split where the shape class allows it, BatchNorm on load for the b layers)
+        flg = _lib.wg_flags(1, 0, int(os.environ.get('WG_BLOCKS', 0)))
+        ran = lib.bdn_conv3x3_wgrad_variant(dt, n, h, w, L.cout, c0, c1, ipg, mode, flg)
+        t = timeit(lambda: _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), L.cout, a0.data_ptr(), c0, a1.data_ptr() if c1 else None, c1,
+                                     mode, bn.data_ptr(), ipg, part.data_ptr(), dw.data_ptr(), L.cin_real, n, h, w, flg, st))
+        line += f' | kernel {ran} {t * 1e6:7.1f} us {fl / t / 1e12:6.1f} TF/s'
+        wt_t += t; wt_f += fl
         t = timeit(lambda: _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), L.cout, a0.data_ptr(), c0, a1.data_ptr() if c1 else None, c1,
                                      0, bn.data_ptr(), ipg, part.data_ptr(), dw.data_ptr(), L.cin_real, n, h, w, 2, st))
         line += f' | reduce {t * 1e6:6.1f} us (ws {part.numel() * 4 / 1e6:.0f} MB)'
         print(line)
-    print(f'wgrad GEMMs on the default schedule (DMA where possible, incl. bnrelu passes) {wt_t * 1e3:.3f} ms  {wt_f / wt_t / 1e12:.1f} TF/s')
+    print(f'wgrad GEMMs on the default plan {wt_t * 1e3:.3f} ms  {wt_f / wt_t / 1e12:.1f} TF/s')
