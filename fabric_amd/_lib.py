@@ -24,6 +24,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     'bdn_last_error': (C.c_char_p, []),
     'bdn_version': (_i, []),
+    'bdn_stream_create': (_i, [_i, C.POINTER(C.c_void_p)]),
+    'bdn_stream_destroy': (_i, [_vp]),
     'bdn_pack_input': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_pack_weights': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'bdn_pack_weights_multi': (_i, [_i, _vp, _i, _vp]),

@@ -135,6 +135,7 @@ class Workspace:
         self._outc_ws = None
         self.logits = None
         self.leased = False        # True while a live autograd graph still needs this workspace's z / bn tables for its backward
+        self.generation = 0        # bumped by every forward that overwrites the buffers (models/bidate_model.py checks it before a backward)
 
     def split_buf(self, which, numel):
         """bf16x3: scratch for a split GEMM operand ([.., 2C] bf16 = hi | lo).  'a' activations and 'd' gradients on the chain's stream;
@@ -187,7 +188,6 @@ class BiDateEngine:
         self._packed_valid = False
         self._pack_desc = None
         self._packed_versions = None
-        self._side = {}            # device -> secondary HIP stream for the weight-gradient GEMMs
         # The only tuning attributes (tools/ab_flag.py A/Bs them in one process).  Everything round 1 and 2 measured and lost -- the
         # unfused BatchNorm-backward paths, relu(bn(z)) materialised for the weight gradient, the two-pass encoder skip backward,
         # release schedules of the weight-gradient GEMMs -- is gone from the product (DESIGN.md section 4 keeps the findings,
@@ -225,10 +225,9 @@ class BiDateEngine:
 
     # ------------------------------------------------------------------ helpers
     def _side_stream(self, device):
-        key = str(device)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=device)
-        return self._side[key]
+        """The process-wide weight-gradient stream of the device (fabric_amd/streams.py)."""
+        from . import streams
+        return streams.get('wgrad', device)
 
     def workspace(self, B, H, W, device):
         """A workspace of this shape that no live autograd graph owns (models/bidate_model.py leases the one its forward
@@ -328,6 +327,7 @@ class BiDateEngine:
         x_d2 = x_d2.contiguous().float()
         B, C, H, W = x_d1.shape
         ws = self.workspace(B, H, W, x_d1.device)
+        ws.generation += 1
         call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, _lib.stream_ptr())
         return self._forward_packed(ws, P, training), ws
 
@@ -347,6 +347,7 @@ class BiDateEngine:
         C, H, W = scene_d1.shape
         n, p = origins.shape[0], patch_size
         ws = self.workspace(n, p, p, scene_d1.device)
+        ws.generation += 1
         call('bdn_gather_tiles', self.dt, ptr(scene_d1), ptr(scene_d2), ptr(origins), ptr(ws.x0),
              n, C, H, W, p, self.cp, _lib.stream_ptr())
         return self._forward_packed(ws, P, False, reuse_eval_bn), ws

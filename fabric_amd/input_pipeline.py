@@ -32,10 +32,18 @@ class DeviceFeeder:
             raise RuntimeError('fabric_amd: DeviceFeeder needs a ROCm device')
         self.device = torch.device(device)
         self.depth = max(2, depth)       # 3: a slot is refilled two steps after it was read (2 slots: +7.5 % step time, 3: +2.5 %)
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        from . import streams
+        self.copy_stream = streams.get('copy', self.device)      # process-wide: a feeder per epoch does not grow the stream count
         self.slots = [_Slot() for _ in range(self.depth)]
         self.pool = ThreadPoolExecutor(max_workers=stage_threads) if stage_threads > 1 else None
         self.stage_threads = stage_threads
+
+    def close(self):
+        """Stop the staging threads and drop the device slots / pinned buffers (the copy stream is process-wide and stays)."""
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+        self.slots = [_Slot() for _ in range(self.depth)]
 
     # ------------------------------------------------------------------ host side
     def _pinned(self, slot, batch):

@@ -15,15 +15,25 @@ from ..engine import BiDateEngine
 
 
 class _Lease:
-    """Marks an engine workspace as owned by one autograd graph; released when the graph (its ctx) is freed, i.e. after
-    backward() without retain_graph, or when the logits are dropped without a backward."""
+    """Marks an engine workspace as owned by one autograd graph.  Released at the END of that graph's backward() -- not when
+    the grad_fn node dies: in the usual loop `logits` / `loss` of the previous iteration are still bound when the next
+    forward runs, and a lease held until then would make the loop ping-pong between two full workspaces -- or, without a
+    backward, when the graph is freed.  A workspace carries a generation counter: a second backward through the same graph
+    (retain_graph=True) after another forward reused the buffers raises instead of reading overwritten activations."""
 
     def __init__(self, ws):
         self.ws = ws
         ws.leased = True
+        self.generation = ws.generation       # engine.forward bumped it when it filled the buffers
+
+    def release(self):
+        if self.ws is not None and self.ws.generation == self.generation:
+            self.ws.leased = False
+        self.ws_released = True
 
     def __del__(self):
-        self.ws.leased = False
+        if not getattr(self, 'ws_released', False):
+            self.release()
 
 
 class _BiDateFunction(torch.autograd.Function):
@@ -52,7 +62,13 @@ class _BiDateFunction(torch.autograd.Function):
         named = list(module.named_parameters())
         P = {k: v.detach() for k, v in module.state_dict(keep_vars=True).items()}
         grads = {k: torch.empty_like(p, dtype=torch.float32) for k, p in named}
+        lease = getattr(ctx, 'lease', None)
+        if lease is not None and ctx.ws.generation != lease.generation:
+            raise RuntimeError('fabric_amd: this graph\'s activations were overwritten by a later forward (second backward with '
+                               'retain_graph=True after another forward of the same shape): re-run the forward')
         eng.backward(ctx.ws, dlogits, P, grads)
+        if lease is not None:
+            lease.release()                   # the activations are dead: the next forward of this shape reuses the workspace
         return (None, None, None) + tuple(grads[k] for k, _ in named)
 
 

@@ -19,6 +19,7 @@ two ranks on one GPU (gloo) and, where two devices are visible, over RCCL.
 """
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 class FlatLayout:
@@ -51,13 +52,16 @@ class GradBucketer:
     keys_no_reduce: gradients that are identically zero on every rank (conv biases in front of a
     BatchNorm) -- they sit at the tail of the layout and are never communicated."""
 
-    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=(), enabled=True, tail_bytes=1 << 20):
+    def __init__(self, layout, flat_grads, n_buckets=4, group=None, keys_no_reduce=(), enabled=True, tail_bytes=1 << 20,
+                 force=False):
         """n_buckets equal slices by bytes, plus one more cut in front of the last `tail_bytes` of gradients: the final
         bucket cannot start before the very last weight gradient of backward exists, so its all-reduce is the one piece of
         communication nothing can hide -- in BiDateNet the last megabyte is the four shallow encoder convs, while an equal
         quarter (13 MB) would also have held back three deep layers that were ready a millisecond earlier."""
         self.layout, self.flat, self.group = layout, flat_grads, group
         self.enabled = enabled                      # False: purely local step even inside an initialised process group
+        self.force = force                          # True: issue the bucket all-reduces even in a world of one rank (a way to run the
+                                                    # RCCL launches, their stream ordering and their cost on a single GPU)
         skip = set(keys_no_reduce)
         keys = [k for k in layout.order if k not in skip]
         assert keys == layout.order[:len(keys)], 'non-reduced gradients must form the tail of the layout'
@@ -103,9 +107,15 @@ class GradBucketer:
             return 1
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def active(self):
+        """Do the buckets go through the process group?"""
+        if not (self.enabled and dist.is_available() and dist.is_initialized()):
+            return False
+        return self.force or dist.get_world_size(self.group) > 1
+
     def on_ready(self, keys):
         """Backward hook: `keys` have just been enqueued on the current stream."""
-        if self.world_size() == 1:
+        if not self.active():
             return
         for k in keys:
             i = self.key_bucket.get(k)
@@ -119,7 +129,7 @@ class GradBucketer:
 
     def finish(self):
         """Launch whatever is left and make the current stream wait for every bucket."""
-        if self.world_size() > 1:
+        if self.active():
             for i, (a, b, _) in enumerate(self.buckets):
                 if not self.launched[i]:
                     self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -134,3 +144,65 @@ def shard_indices(n_items, rank, world_size):
     (the tail is dropped) so all ranks run the same number of steps."""
     per = n_items // world_size
     return list(range(rank, per * world_size, world_size))
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Epoch-aware disjoint shards of a dataset's indices (DistributedSampler's contract): every rank derives the SAME
+    permutation from (seed, epoch) -- a private torch.Generator, independent of any per-process RNG state -- and takes
+    positions rank, rank + world, ...  All ranks together visit every item at most once per epoch (the tail n % world is
+    dropped so that every rank runs the same number of steps); call set_epoch(e) before each epoch for a new permutation.
+    The reference's single-process DataParallel loop visits every patch each epoch (train.py:73-85)."""
+
+    def __init__(self, n_items, rank=0, world_size=1, seed=0, shuffle=True):
+        if not 0 <= rank < world_size:
+            raise ValueError(f'rank {rank} outside world of {world_size}')
+        self.n, self.rank, self.world, self.seed, self.shuffle = int(n_items), rank, world_size, int(seed), shuffle
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.n // self.world
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed * 1000003 + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        return iter(order[i] for i in shard_indices(self.n, self.rank, self.world))
+
+
+def allreduce_mean_grads(params, world_size, group=None, bucket_bytes=16 << 20):
+    """Average the `.grad` of `params` over the ranks with a few large all-reduces instead of one blocking call per tensor
+    (BiDateNet has 74 parameter tensors, 53.6 MB): gradients are packed into contiguous buckets of ~bucket_bytes in REVERSE
+    parameter order (the order backward produced them), each bucket is reduced asynchronously while the next one is being
+    packed, then scaled by 1 / world and copied back.  Used by the autograd training loop (train_epoch_autograd); the fused
+    TrainStep reduces slices of its flat gradient buffer in place (GradBucketer) and needs no packing."""
+    if world_size <= 1:
+        return 0
+    grads = [p.grad for p in reversed(list(params)) if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        cur.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    inflight = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        inflight.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
+    inv = 1.0 / world_size
+    for work, flat, b in inflight:
+        work.wait()
+        off = 0
+        for g in b:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g)).mul_(inv)
+            off += n
+    return len(buckets)

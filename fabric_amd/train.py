@@ -20,7 +20,7 @@ from .models.bidate_model import BiDateNet
 from .train_step import TrainStep
 from .utils.dataloaders import OneraPreloader, metadata_from_shapes, synthetic_onera
 from .utils.helpers import get_mean_metrics, initialize_metrics, set_metrics
-from .utils.metrics import TverskyLoss, batch_prf_from_counts
+from .utils.metrics import batch_prf_from_counts
 
 DEFAULTS = dict(patch_size=90, stride=180, augmentation=True, num_workers=2, epochs=1, batch_size=32,
                 learning_rate=1e-3, loss_function='tversky', tversky_alpha=0.1, tversky_beta=0.9,
@@ -28,18 +28,22 @@ DEFAULTS = dict(patch_size=90, stride=180, augmentation=True, num_workers=2, epo
 
 
 def make_loaders(full_load, val_cities, patch_size, stride, batch_size, augmentation, num_workers=0,
-                 rank=0, world_size=1):
-    """utils/helpers.py:211-258 (get_loaders) given an already loaded dataset dict; the training index list is
-    sharded stride-by-rank for data-parallel runs."""
-    from .parallel import shard_indices
+                 rank=0, world_size=1, seed=0):
+    """utils/helpers.py:211-258 (get_loaders) given an already loaded dataset dict.  For data-parallel runs the training
+    indices are sharded by a ShardSampler: every rank derives the same epoch permutation from (seed, epoch) and takes a
+    disjoint stride-by-rank slice of it -- independent of the per-process `random` state that OneraPreloader's in-place
+    shuffle (utils/dataloaders.py:171) consumes, and sorted first so that the reference's set-ordered city list
+    (utils/dataloaders.py:55) cannot differ between ranks.  Call `train_loader.sampler.set_epoch(e)` every epoch."""
+    from .parallel import ShardSampler
     shapes = {c: d['labels'].shape for c, d in full_load.items()}
     train_meta, val_meta = metadata_from_shapes(shapes, val_cities, patch_size, stride)
+    train_meta = sorted(train_meta)                        # rank-independent base order; the sampler owns the shuffling
     train_ds = OneraPreloader('', train_meta, full_load, patch_size, augmentation)
+    train_ds.imgs.sort()                                   # undo the constructor's process-local shuffle (same list object)
     val_ds = OneraPreloader('', val_meta, full_load, patch_size, False)
-    if world_size > 1:
-        train_ds = torch.utils.data.Subset(train_ds, shard_indices(len(train_ds), rank, world_size))
+    sampler = ShardSampler(len(train_ds), rank, world_size, seed=seed)
     kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=True)   # pinned batches: the copy stream DMAs them without staging
-    return (torch.utils.data.DataLoader(train_ds, shuffle=True, drop_last=True, **kw),
+    return (torch.utils.data.DataLoader(train_ds, sampler=sampler, drop_last=True, **kw),
             torch.utils.data.DataLoader(val_ds, shuffle=False, **kw))
 
 
@@ -63,42 +67,41 @@ def train_epoch(step, loader, dev, patch_size, feeder=None):
 
 
 @torch.no_grad()
-def validate(model, loader, dev, patch_size, alpha, beta):
-    """train.py:125-172: eval-mode forward, Tversky loss, per-batch accuracy / P / R / F1, mean over batches."""
+def validate(model, loader, dev, patch_size, criterion, feeder=None):
+    """train.py:125-172: eval-mode forward, the SAME criterion the run optimises (train.py:137), per-batch accuracy / P / R / F1,
+    mean over batches.  Batches arrive through the feeder's copy stream when one is given."""
+    from .utils.metrics import confusion_counts
     model.eval()
-    crit = TverskyLoss(alpha=alpha, beta=beta)
     metrics = initialize_metrics()
-    for b1, b2, labels in loader:
-        labels = labels.to(dev)
-        logits = model(b1.to(dev), b2.to(dev))
-        loss = crit(logits, labels.long())
-        c = crit.last_counts.cpu()
+    batches = feeder(loader) if feeder is not None else ((b1.to(dev), b2.to(dev), lb.to(dev)) for b1, b2, lb in loader)
+    for b1, b2, labels in batches:
+        logits = model(b1, b2)
+        loss = criterion(logits, labels.long())
+        c = confusion_counts(logits, labels).cpu()
         metrics = set_metrics(metrics, loss.item(), 100.0 * int(c[3]) / (labels.shape[0] * patch_size ** 2),
                               batch_prf_from_counts(c))
     return get_mean_metrics(metrics)
 
 
-def train_epoch_autograd(model, criterion, optimizer, loader, dev, patch_size, world=1):
+def train_epoch_autograd(model, criterion, optimizer, loader, dev, patch_size, world=1, feeder=None):
     """The reference loop itself (train.py:83-101) for the criteria the fused step does not cover (dice / jaccard / focal):
     autograd through the one-node BiDateNet function, torch.optim.SGD, gradients averaged over the ranks after backward."""
-    import torch.distributed as dist
+    from .parallel import allreduce_mean_grads
     from .utils.metrics import batch_prf_from_counts, confusion_counts
     model.train()
     metrics = initialize_metrics()
-    for b1, b2, labels in loader:
-        labels = labels.to(dev)
+    batches = feeder(loader) if feeder is not None else ((b1.to(dev), b2.to(dev), lb.to(dev)) for b1, b2, lb in loader)
+    for b1, b2, labels in batches:
         optimizer.zero_grad()
-        logits = model(b1.to(dev), b2.to(dev))
+        logits = model(b1, b2)
         loss = criterion(logits, labels.long())
         loss.backward()
-        if world > 1:
-            for p in model.parameters():
-                dist.all_reduce(p.grad)
-                p.grad /= world
+        allreduce_mean_grads(model.parameters(), world)     # a few 16 MB buckets, not 74 blocking per-tensor calls
         optimizer.step()
         model.engine().invalidate_weights()
         c = confusion_counts(logits.detach(), labels).cpu()
         metrics = set_metrics(metrics, loss.item(), 100.0 * int(c[3]) / (labels.shape[0] * patch_size ** 2), batch_prf_from_counts(c))
+        del logits, loss                                    # the graph (and its workspace lease) dies before the next forward
     return get_mean_metrics(metrics)
 
 
@@ -129,6 +132,7 @@ def main(argv=None):
             ap.add_argument(f'--{k}', type=type(v), default=v)
     ap.add_argument('--synthetic', action='store_true', help='use fabric_amd.utils.dataloaders.synthetic_onera()')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--seed', type=int, default=0, help='seeds the shard permutation, the augmentation draws and the initial weights identically on every rank')
     ap.add_argument('--focal_gamma', type=float, default=None, help='required by --loss_function focal (utils/helpers.py:291)')
     ap.add_argument('--metadata', default=None, help="JSON in the reference's metadata.json schema (band_ids, band_means, "
                                                      "band_stds, ...): its entries become defaults like utils/parser.py:7-10")
@@ -157,6 +161,9 @@ def main(argv=None):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    import random
+    random.seed(opt.seed)                                  # same dataset order / initial weights on every rank; augmentation draws
+    torch.manual_seed(opt.seed)                            # (global `random`, utils/dataloaders.py:150-156) are re-seeded per rank below
     scenes = None
     if opt.synthetic:
         data = synthetic_onera(n_cities=6, bands=13, size=(360, 360))
@@ -170,14 +177,18 @@ def main(argv=None):
         data = {c: {'images': d['images'].cpu().numpy(), 'labels': d['labels']} for c, d in scenes.items()}
         val_cities = [c for c in opt.validation_cities if c in data]
     train_loader, val_loader = make_loaders(data, val_cities, opt.patch_size, opt.stride // 2 if opt.synthetic else opt.stride,
-                                            opt.batch_size, opt.augmentation, rank=rank, world_size=world)
+                                            opt.batch_size, opt.augmentation, num_workers=opt.num_workers,
+                                            rank=rank, world_size=world, seed=opt.seed)
+    random.seed(opt.seed * 7919 + rank)                    # different augmentation draws per rank from here on
     model = BiDateNet(len(opt.band_ids) if opt.band_ids else 13, 2, precision=opt.precision).to(dev)
     fused = opt.loss_function == 'tversky'
+    from .input_pipeline import DeviceFeeder
+    from .utils.helpers import get_criterion
+    feeder = DeviceFeeder(dev)                             # ONE feeder (copy stream, staging threads, device slots) for the whole run
+    criterion = get_criterion(opt)                         # validation reports the criterion the run optimises (train.py:137)
     if fused:
         step = TrainStep(model, lr=opt.learning_rate, tversky_alpha=opt.tversky_alpha, tversky_beta=opt.tversky_beta)
     else:
-        from .utils.helpers import get_criterion
-        criterion = get_criterion(opt)
         optimizer = torch.optim.SGD(model.parameters(), lr=opt.learning_rate)      # train.py:55
         if world > 1:
             for p in model.parameters():
@@ -185,11 +196,12 @@ def main(argv=None):
     best = {'cd_f1scores': -1, 'cd_recalls': -1, 'cd_precisions': -1}              # train.py:62
     run_meta = dict(meta, **{k: getattr(opt, k) for k in DEFAULTS}, precision=opt.precision, world_size=world)
     for epoch in range(opt.epochs):
+        train_loader.sampler.set_epoch(epoch)
         if fused:
-            tr = train_epoch(step, train_loader, dev, opt.patch_size)
+            tr = train_epoch(step, train_loader, dev, opt.patch_size, feeder)
         else:
-            tr = train_epoch_autograd(model, criterion, optimizer, train_loader, dev, opt.patch_size, world)
-        va = validate(model, val_loader, dev, opt.patch_size, opt.tversky_alpha, opt.tversky_beta)
+            tr = train_epoch_autograd(model, criterion, optimizer, train_loader, dev, opt.patch_size, world, feeder)
+        va = validate(model, val_loader, dev, opt.patch_size, criterion, feeder)
         if rank == 0:
             print(json.dumps({'epoch': epoch, **{'train_' + k: float(v) for k, v in tr.items()},
                               **{'validate_' + k: float(v) for k, v in va.items()}}), flush=True)
@@ -204,6 +216,7 @@ def main(argv=None):
                 ingest.write_png_gray(os.path.join(opt.log_dir, f'{city}_epoch_{epoch}.png'), (mask * 255).cpu().numpy())
         if rank == 0:                                          # replica 0's BatchNorm buffers, like DataParallel
             best = save_if_better(model, va, best, run_meta, epoch, opt.log_dir)
+    feeder.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -20,7 +20,7 @@ from .parallel import FlatLayout, GradBucketer
 
 class TrainStep:
     def __init__(self, model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, eps=1e-7,
-                 process_group=None, n_buckets=4, distributed=True):
+                 process_group=None, n_buckets=4, distributed=True, force_collectives=False):
         self.model, self.lr = model, lr
         self.alpha, self.beta, self.eps = tversky_alpha, tversky_beta, eps
         self.group = process_group
@@ -44,7 +44,7 @@ class TrainStep:
         self.grads = {k: self.layout.view(self.flat_grads, k) for k, _ in named}
         bias_tail = [k for k in order if k.endswith('.bias') and k.split('.')[-2] in ('0', '3')]
         self.bucketer = GradBucketer(self.layout, self.flat_grads, n_buckets, process_group, keys_no_reduce=bias_tail,
-                                     enabled=self.world > 1)
+                                     enabled=self.world > 1 or force_collectives, force=force_collectives)
         if self.world > 1:                                   # identical start on every rank (DataParallel broadcasts)
             dist.broadcast(self.flat_params, src=0, group=process_group)
         self._tv = None
@@ -79,11 +79,13 @@ class TrainStep:
         return loss
 
     def stream(self, device=None):
-        """The high-priority stream the step's chain runs on.  A training loop that makes it the current stream
-        (``with torch.cuda.stream(step.stream()): ...``) saves the two cross-stream joins per step (~25 us of idle GPU)."""
+        """The high-priority stream the step's chain runs on: the process-wide 'chain' stream of the device (fabric_amd/streams.py;
+        every TrainStep shares it, so the N-th instance of a process is as fast as the first).  A training loop that makes it
+        the current stream (``with torch.cuda.stream(step.stream()): ...``) saves the two cross-stream joins per step
+        (~25 us of idle GPU)."""
         if self._hp is None:
-            dev = device if device is not None else self.flat_params.device
-            self._hp = torch.cuda.Stream(device=dev, priority=-1)
+            from . import streams
+            self._hp = streams.get('chain', device if device is not None else self.flat_params.device)
         return self._hp
 
     def _step(self, x_d1, x_d2, labels):

@@ -123,10 +123,14 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
     Returns a uint8 [H,W] device tensor equal to ``_get_bands(argmax(model(tiles)))`` of the reference loop.
     shard=(rank, world): process only this rank's contiguous slice of the tile list; merge=True then combines
     the per-rank masks with one all-reduce(MAX) over the default process group (unwritten pixels are 0).
-    batch_size: tiles per forward batch (256 is the fastest on MI355X, bench.py scene leg); every activation tensor must stay below
-    4 GB (2 * batch_size * patch_size^2 * 64 channels * 2 bytes), i.e. at most 1023 tiles of 128 x 128."""
-    if 2 * batch_size * patch_size * patch_size * 64 * 2 >= 1 << 32:
-        raise ValueError(f'batch_size={batch_size} tiles of {patch_size} px make a 4 GB activation tensor; use a smaller batch')
+    batch_size: tiles per forward batch (256 is the fastest on MI355X, bench.py scene leg).  Every tensor a kernel addresses must
+    stay below 4 GB (32-bit byte offsets); the widest one is the operand of a 64-channel full-resolution layer at 2 * batch_size
+    images: 64 channels x 2 bytes in the bf16 setting (<= 1023 tiles of 128 x 128), 64 x 4 bytes in fp32 (<= 511) and the
+    [hi | lo] split of the concatenated 128-channel decoder input, 256 x 2 bytes at batch_size images, in bf16x3 (<= 511)."""
+    eng_ = model.engine()
+    widest = max(2 * batch_size * 64 * eng_.esize, batch_size * 2 * 128 * 2 if eng_.x3 else 0)      # bytes per pixel position of the widest tensor
+    if widest * patch_size * patch_size >= 1 << 32:
+        raise ValueError(f'batch_size={batch_size} tiles of {patch_size} px make a 4 GB tensor in the {eng_.precision} setting; use a smaller batch')
     P = _eval_params(model)
     eng = model.engine()
     dev = next(model.parameters()).device

@@ -37,6 +37,14 @@ enum { BDN_IN_PLAIN = 0, BDN_IN_BNRELU = 1 };
 const char* bdn_last_error(void);
 int bdn_version(void);
 
+/* ---- streams of the training step (reference: none -- train.py:83-101 runs on PyTorch's default stream) ----
+ * A HIP stream on the calling thread's current device, created by the library so that its hardware-queue placement does not
+ * depend on the host framework's stream pool: the step's dependency chain (priority 1 = high), its weight-gradient GEMMs and
+ * its host -> device copies (priority 0) each get one, shared by every step object of the process (fabric_amd/streams.py).
+ * The caller owns the stream and destroys it with bdn_stream_destroy. */
+int bdn_stream_create(int priority, void** stream_out);
+int bdn_stream_destroy(void* stream);
+
 /* ---- layout converters (boundary of BiDateNet.forward, models/bidate_model.py:22) ---- */
 /* x_d1, x_d2: [B,C,H,W] f32 NCHW  ->  out: [2B,H,W,Cpad] (date-1 images first), channels >= C zeroed. */
 int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,

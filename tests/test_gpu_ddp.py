@@ -108,7 +108,7 @@ def test_fp32_two_ranks_delayed_side_stream(tmp_path):
 
 
 def test_bf16x3_two_ranks(tmp_path):
-    """The split-operand setting runs its weight gradients on the main stream: every bucket is released from there."""
+    """The split-operand setting: weight gradients on the second stream with their own operand-split buffers, like bf16."""
     _run(tmp_path, 'bf16x3', 13, False)
 
 
@@ -116,3 +116,61 @@ def test_bf16x3_two_ranks(tmp_path):
 @pytest.mark.parametrize('delay', [False, True])
 def test_bf16_13band_two_ranks_over_rccl(tmp_path, delay):
     _run(tmp_path, 'bf16', 13, delay, backend='nccl')
+
+
+_RCCL1 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from fabric_amd import BiDateNet
+from fabric_amd.train_step import TrainStep
+from oracle import filler
+delay = sys.argv[3] == '1'
+b, c, s = 8, 13, 64
+x1, x2, lbl = (torch.from_numpy(v).cuda() for v in filler.make_inputs(b, c, s, seed=21))
+res = []
+for force in (False, True):
+    model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
+    ts = TrainStep(model, lr=0.05, force_collectives=force)
+    assert ts.bucketer.active() == force and len(ts.bucketer.buckets) == 5
+    launched = []
+    if force:
+        orig = dist.all_reduce
+        def counting(t, *a, **k):
+            launched.append(t.numel())
+            return orig(t, *a, **k)
+        dist.all_reduce = counting
+    side = model.engine()._side_stream(torch.device('cuda', 0))
+    with torch.cuda.stream(ts.stream()):
+        for _ in range(4):
+            if delay:                       # weight-gradient stream ~20 ms behind: a bucket not ordered behind it would reduce stale gradients
+                with torch.cuda.stream(side):
+                    torch.cuda._sleep(40_000_000)
+            ts.step(x1, x2, lbl)
+    torch.cuda.synchronize()
+    if force:
+        dist.all_reduce = orig
+        assert len(launched) == 4 * 5 and sum(launched[:5]) == ts.bucketer.reduce_end, launched[:5]
+    res.append(ts.flat_params.cpu().clone())
+assert torch.equal(res[0], res[1]), (res[0] - res[1]).abs().max()      # a sum over one rank changes nothing, in any order
+dist.barrier(); dist.destroy_process_group()
+print('ok')
+'''
+
+
+@pytest.mark.parametrize('delay', [False, True])
+def test_bucket_allreduces_through_rccl_with_one_rank(tmp_path, delay):
+    """RCCL on the real stream arrangement with the one GPU a test box has: process group 'nccl', world size 1, the five
+    bucket all-reduces FORCED (TrainStep(force_collectives=True)) so that every step initialises / launches / orders them
+    exactly as an 8-GPU run does -- from the weight-gradient stream, and the last bucket from the chain's stream after it
+    joined the weight-gradient stream.  Four steps must not deadlock and must leave the parameters bit-identical to the
+    purely local step, also with the weight-gradient stream parked behind a 20 ms sleep kernel before every step."""
+    script = tmp_path / 'rccl1_worker.py'
+    script.write_text(_RCCL1)
+    port = str(33000 + (os.getpid() * 3 + int(delay)) % 2000)
+    p = subprocess.Popen([sys.executable, str(script), ROOT, port, '1' if delay else '0'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = p.communicate(timeout=280)[0].decode()
+    assert p.returncode == 0 and 'ok' in out, out

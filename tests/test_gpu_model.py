@@ -149,10 +149,17 @@ def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, pre
         if k.endswith('running_mean') or 'num_batches' in k:
             continue
         assert (p.grad - want).abs().max() <= 1e-5 * want.abs().max() + 1e-9, k
-    del la, lb
-    # the graphs are gone: their workspaces are free again and the next forward reuses the first one
+    # backward is over: the leases are released although `la` / `lb` (and their graphs) are still bound -- the usual training
+    # loop keeps the previous iteration's loss alive while the next forward runs and must not ping-pong between two workspaces
     ws_pool = model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device))]
     assert not any(w.leased for w in ws_pool)
+    lc = _tversky_torch(model(x1, x2), lbl)
+    assert len(ws_pool) == 2 and ws_pool[0].leased
+    lc.backward(retain_graph=True)
+    model(y1, y2)                                       # reuses the released workspace ...
+    with pytest.raises(RuntimeError, match='overwritten'):
+        lc.backward()                                   # ... so a second backward through the old graph must refuse
+    del la, lb, lc
 
 
 @pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90'])

@@ -135,7 +135,7 @@ def test_patch_origin_rule():
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[3])
-from fabric_amd.parallel import FlatLayout, GradBucketer, shard_indices
+from fabric_amd.parallel import FlatLayout, GradBucketer, ShardSampler, allreduce_mean_grads, shard_indices
 from fabric_amd.engine import param_order
 from fabric_amd import BiDateNet
 rank, world = int(sys.argv[1]), int(sys.argv[2])
@@ -165,6 +165,34 @@ for step in range(2):
         assert torch.all(v == (0.0 if k in tail else expect)), (k, v.flatten()[0].item(), expect)
 idx = [shard_indices(103, r, world) for r in range(world)]
 assert all(len(i) == 103 // world for i in idx) and len(set(sum(idx, []))) == (103 // world) * world
+# the autograd loop's gradient exchange: a few packed buckets, every .grad ends up as the mean over the ranks
+torch.manual_seed(5)
+ref = [torch.randn(p.shape) for p in m.parameters()]
+for p, r in zip(m.parameters(), ref):
+    p.grad = r * (rank + 1)
+nb = allreduce_mean_grads(m.parameters(), world, bucket_bytes=16 << 20)
+assert 1 <= nb <= 5, nb                                   # 53.6 MB of gradients: four buckets, not 74 calls
+mean = sum(r + 1 for r in range(world)) / world
+for p, r in zip(m.parameters(), ref):
+    assert torch.allclose(p.grad, r * mean, rtol=1e-6, atol=1e-7)
+# epoch-aware shards: this rank's indices are disjoint from the other rank's, together they cover the list, and every rank
+# derives them WITHOUT touching the global RNG state (rank 1 burns some draws first)
+import random
+if rank == 1:
+    random.random(); torch.rand(3)
+mine = []
+for epoch in range(2):
+    smp = ShardSampler(103, rank, world, seed=7)
+    smp.set_epoch(epoch)
+    mine.append(list(smp))
+gathered = [None] * world
+dist.all_gather_object(gathered, mine)
+for epoch in range(2):
+    shards = [g[epoch] for g in gathered]
+    flat_idx = sum(shards, [])
+    assert all(len(sh) == 103 // world for sh in shards)
+    assert len(set(flat_idx)) == len(flat_idx) == (103 // world) * world          # disjoint; at most world - 1 items dropped
+assert gathered[0][0] != gathered[0][1]                                            # reshuffled per epoch
 dist.barrier(); dist.destroy_process_group()
 print('ok', rank)
 '''

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep
+from fabric_amd import streams
 torch.manual_seed(0)
 dev = torch.device('cuda:0')
 model = BiDateNet(13, 2, precision='bf16').cuda().train()
@@ -21,7 +22,7 @@ res = {k: [] for k in combos}
 for rep in range(4):
     for name, (c, s) in combos.items():
         step._hp = c
-        eng._side[str(dev)] = s
+        streams._streams[(dev.index or 0, 'wgrad')] = s
         with torch.cuda.stream(c):
             for _ in range(4): step.step(x1, x2, lbl)
             torch.cuda.synchronize()

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep
+from fabric_amd import streams
 B = 64
 torch.manual_seed(0)
 model = BiDateNet(13, 2).cuda().train()
@@ -22,7 +23,7 @@ key = str(x1.device)
 res = []
 for k in range(12):                      # the next normal-priority pool streams as the weight-gradient stream
     s = torch.cuda.Stream()
-    eng._side[key] = s
+    streams._streams[(x1.device.index or 0, 'wgrad')] = s
     res.append((k, hex(s.cuda_stream)[-6:], t_res()))
 print('side stream candidates', res)
 best = min(res, key=lambda r: r[2])
