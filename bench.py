@@ -13,7 +13,9 @@ Extra objects on the same line:
                  the launch stream inside the timed region (one launch bracketed per step, every launch shape weighted
                  equally), against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); HBM bytes per launch and
                  per step from the committed PMC passes (profiles/);
-  cpu_baseline   the oracle's stock-torch assembly of the reference graph timed on ALL host cores (rank 0, N=1 only);
+  cpu_baseline   the oracle's stock-torch assembly of the reference graph timed on the host cores (rank 0, N=1 only): median of 5
+                 steps at B=16 and at B=4, at the fastest thread count;
+  collectives    the same step with its five gradient-bucket all-reduces forced through RCCL (one rank), timed beside the local step;
   host_fed       the same step fed from pinned HOST memory through fabric_amd.input_pipeline.DeviceFeeder (PCIe inclusive);
   parity_setting pairs/s of the two float32-class settings (bf16x3: logits within 1e-3; fp32: exact f32 MFMA);
   scene          BASELINE configs[4]: full-scene sliding-window inference of a 13-band 10000 x 10000 scene pair.
@@ -49,60 +51,71 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(seconds_budget=28.0):
-    """Reference CPU path (oracle port) on the host cores: fwd + Tversky + bwd + SGD, fp32, B=16.
-    "All cores" is tried, but so are smaller thread counts: stock torch/oneDNN gets SLOWER past one thread per physical core
-    on the big two-socket hosts (256 logical CPUs: 0.17 pairs/s against 4.7 with 64 threads), and a baseline should be the
-    reference's best configuration.  The best is reported as `value` with its thread count in `cores`; every count tried is
-    listed in `sample`."""
+def cpu_baseline(search_budget=30.0, confirm_budget=60.0):
+    """Reference CPU path (oracle port) on the host cores: fwd + Tversky + bwd + SGD, fp32 (B=16 and B=4, median of
+    >= 5 timed steps after warm-up).  Phase 1 searches the thread count with short runs at B=16 -- "all cores" is tried, but so are
+    smaller counts: stock torch/oneDNN gets SLOWER past one thread per physical core on the big two-socket hosts (256 logical CPUs:
+    0.17 pairs/s against 4.7 with 64 threads), and a baseline should be the reference's best configuration.  Phase 2 times the best
+    count properly: 5 steps at B=16 (`value`) and 5 steps at B=4 (`b4`).  Every count tried is listed in `sample`."""
     from oracle import bidate_oracle as O
     from oracle import filler
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         ncores = os.cpu_count() or 1
-    B = 16
-    x1, x2, lbl = filler.make_inputs(B, 13, 128, seed=0)
-    x1, x2, lbl = torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl).long()
     net = O.build_torch_baseline(13, 2).train()
     opt = torch.optim.SGD(net.parameters(), lr=1e-3)
 
-    def step():
+    def make(B):
+        x1, x2, lbl = filler.make_inputs(B, 13, 128, seed=0)
+        return torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl).long()
+
+    def step(batch):
         opt.zero_grad()
-        loss = O.tversky_loss(net(x1, x2), lbl, 0.1, 0.9)
+        loss = O.tversky_loss(net(batch[0], batch[1]), batch[2], 0.1, 0.9)
         loss.backward()
         opt.step()
 
+    def timed(batch, n, budget):
+        t_begin = time.perf_counter()
+        step(batch)                                   # warm-up (oneDNN primitive creation for this thread count / shape)
+        warm = time.perf_counter() - t_begin
+        times = []
+        while len(times) < n and (not times or time.perf_counter() - t_begin + times[-1] < budget):
+            t0 = time.perf_counter()
+            step(batch)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        return (times[len(times) // 2] if times else warm), len(times)
+
+    b16, b4 = make(16), make(4)
     tried, t_start = [], time.perf_counter()
     cands = []
     for th in (min(ncores, 64), max(1, ncores // 2), ncores, min(ncores, 32)):     # 64 first: one thread per core of one socket
         if th not in cands:
             cands.append(th)
     for th in cands:
-        left = seconds_budget - (time.perf_counter() - t_start)
+        left = search_budget - (time.perf_counter() - t_start)
         done_ = [t for t in tried if t[1] is not None]
         # skip a count that cannot finish warm-up + 2 steps in what is left of the budget, or once adding threads made it slower
         if done_ and (left < 3.5 * done_[-1][1] or done_[-1][1] > 1.3 * min(t[1] for t in done_)):
             tried.append((th, None, 0))
             continue
         torch.set_num_threads(th)
-        t0 = time.perf_counter()
-        step()                                        # warm-up (oneDNN primitive creation for this thread count)
-        warm = time.perf_counter() - t0
-        times = []
-        while len(times) < 2 and (time.perf_counter() - t_start) < seconds_budget and (len(times) < 1 or warm < 6.0):
-            t0 = time.perf_counter()
-            step()
-            times.append(time.perf_counter() - t0)
-        times.sort()
-        tried.append((th, times[len(times) // 2] if times else warm, len(times)))
-    done = [t for t in tried if t[1] is not None]
-    best = min(done, key=lambda t: t[1])
-    listing = ', '.join(f'{th} threads: ' + (f'{B / t:.2f} pairs/s ({n} steps)' if t is not None else 'skipped (budget / already slower with fewer threads)') for th, t, n in tried)
-    return {'value': B / best[1], 'unit': 'patch-pairs/s', 'cores': best[0], 'kind': 'port',
-            'sample': f'B={B} 13x128x128 fwd+Tversky+bwd+SGD steps, fp32 stock torch.nn assembly of the reference graph '
-                      f'(oracle.build_torch_baseline, pinned to the golden logits by tests/test_oracle_cpu.py), median per thread count, '
-                      f'best reported; host has {ncores} usable CPUs ({_cpu_model()}); {listing}'}
+        t, n = timed(b16, 2, max(left, 1.0))
+        tried.append((th, t, n))
+    best_th = min((t for t in tried if t[1] is not None), key=lambda t: t[1])[0]
+    torch.set_num_threads(best_th)
+    t16, n16 = timed(b16, 5, confirm_budget * 0.75)
+    t4, n4 = timed(b4, 5, confirm_budget * 0.25)
+    listing = ', '.join(f'{th} threads: ' + (f'{16 / t:.2f} pairs/s ({n} steps)' if t is not None else 'skipped (budget / already slower with fewer threads)') for th, t, n in tried)
+    return {'value': 16 / t16, 'unit': 'patch-pairs/s', 'cores': best_th, 'kind': 'port',
+            'b4': {'value': 4 / t4, 'unit': 'patch-pairs/s', 'timed_steps': n4, 'ms_per_step': t4 * 1e3},
+            'timed_steps': n16, 'ms_per_step': t16 * 1e3,
+            'sample': f'13x128x128 fwd+Tversky+bwd+SGD steps, fp32 stock torch.nn assembly of the reference graph (oracle.build_torch_baseline, '
+                      f'pinned to the golden logits by tests/test_oracle_cpu.py): median of {n16} timed steps at B=16 (value) and of {n4} at B=4 (b4) '
+                      f'after one warm-up step each, at the fastest thread count of a short search; host has {ncores} usable CPUs '
+                      f'({_cpu_model()}); search at B=16: {listing}'}
 
 
 # ---------------------------------------------------------------------------------------------- committed profile artefacts
@@ -213,6 +226,41 @@ def host_fed_leg(ts, dev, B, C, S, steps, warmup, x1, x2, lbl):
                    'PCIe-inclusive, never the headline value; vs_resident = resident loop timed right before and after / fed loop'}
 
 
+def collectives_leg(ts, model, dev, x1, x2, lbl, steps):
+    """The step with its five gradient-bucket all-reduces really issued through RCCL -- process group 'nccl' with ONE rank, the
+    buckets forced (TrainStep(force_collectives=True)) -- on the stream arrangement an 8-GPU run uses: launched from the
+    weight-gradient stream behind the GEMM that completes a bucket, the last one from the chain's stream.  With one rank RCCL has
+    nothing to exchange, so this prices the launches, the stream hand-offs and RCCL's own kernels beside two busy queues, not the
+    xGMI transfer (53.6 MB per step; DESIGN.md section 5 prices that from the link rate).  Timed against the local step right
+    before and after it in the same process."""
+    from fabric_amd.train_step import TrainStep
+    own_group = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(29000 + os.getpid() % 3000))
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+            own_group = True
+        forced = TrainStep(model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, force_collectives=True)
+        n = max(steps // 2, 10)
+        a = _time_steps(ts, x1, x2, lbl, 3, n) * 1e3
+        f = _time_steps(forced, x1, x2, lbl, 5, n) * 1e3
+        b = _time_steps(ts, x1, x2, lbl, 3, n) * 1e3
+        local = 0.5 * (a + b)
+        sizes = [(hi - lo) * 4 for lo, hi, _ in forced.bucketer.buckets]
+        out = {'ms_per_step': f, 'local_ms_per_step_adjacent': local, 'overhead_frac': f / local - 1.0,
+               'buckets': len(sizes), 'bucket_bytes': sizes, 'backend': 'nccl (RCCL), world size 1, all-reduces forced',
+               'what_it_prices': 'launch + stream ordering + RCCL kernels beside the two busy queues; NOT the xGMI transfer'}
+        del forced
+        return out
+    except Exception as e:                                    # a bench line without this leg beats no bench line
+        return {'error': f'{type(e).__name__}: {e}'}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def parity_leg(dev, B, C, S):
     """The float32-class settings at the benchmark shape: pairs/s, and how far bf16x3 / bf16 logits sit from the exact-f32
     setting on the same weights and inputs (the f32 setting itself is pinned to the reference within 3e-5 by tests/)."""
@@ -295,7 +343,15 @@ def main():
     ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP events')
     ap.add_argument('--no-extras', action='store_true', help='skip the host_fed / parity_setting / scene legs')
     ap.add_argument('--scene-size', type=int, default=10000)
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='N=1 only: the HEADLINE loop itself issues its gradient-bucket all-reduces through RCCL (world size 1)')
     args = ap.parse_args()
+
+    # the contract is ONE JSON line on stdout: keep a private handle on the real stdout for it and point file descriptor 1 at stderr
+    # for everything else (RCCL prints a version banner through C stdio, which would otherwise land after the JSON line at exit)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -309,13 +365,18 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.force_collectives and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29000 + os.getpid() % 3000))
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 
     from fabric_amd import BiDateNet
     from fabric_amd.train_step import TrainStep
 
     torch.manual_seed(1234)                  # same random-init weights on every rank
     model = BiDateNet(args.channels, 2, precision=args.precision).to(dev).train()
-    ts = TrainStep(model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9)
+    ts = TrainStep(model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, force_collectives=args.force_collectives)
     g = torch.Generator(device='cpu').manual_seed(100 + rank)     # each rank its own shard of synthetic pairs
     B, S, C = args.batch, args.size, args.channels
     x1 = torch.randn(B, C, S, S, generator=g)
@@ -414,7 +475,8 @@ def main():
             'config': {'workload': f'BiDateNet({C},2) {C}-band {S}x{S} patch pairs, batch {B}/GPU, '
                                    f'fwd + Tversky + bwd + grad all-reduce + SGD (BASELINE configs[{1 if world == 1 else 2}])',
                        'global_batch': B * world, 'patch': S, 'bands': C,
-                       'parallelism': f'dp{world}', 'precision': args.precision, 'inputs': 'resident in HBM'},
+                       'parallelism': f'dp{world}', 'precision': args.precision, 'inputs': 'resident in HBM',
+                       **({'collectives': 'forced through RCCL with one rank'} if args.force_collectives and world == 1 else {})},
             'step_mfma_frac': value * FLOP_PER_PAIR_FWD_BWD / (world * peak),
             'final_loss': loss_val,
             'host_enqueue_ms_per_step': enqueue_s / args.steps * 1e3,
@@ -426,6 +488,8 @@ def main():
             out['hbm_frac'] = hb[0] / (ms_step * 1e-3) / HBM_PEAK
             out['hbm_source'] = hb[1] + ' (PMC FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of a step; bytes/step divided by this run\'s step time and 8 TB/s)'
         if world == 1 and not args.no_extras and args.precision == 'bf16':
+            if not args.force_collectives:
+                out['collectives'] = collectives_leg(ts, model, dev, x1, x2, lbl, args.steps)
             out['host_fed'] = host_fed_leg(ts, dev, B, C, S, args.steps, args.warmup, x1, x2, lbl)
             del ts, model, eng, x1, x2, lbl
             torch.cuda.empty_cache()
@@ -433,8 +497,9 @@ def main():
             out['scene'] = scene_leg(dev, size=args.scene_size)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
