@@ -285,8 +285,6 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
             A_MMA(ao, b0_, b1_)                                                                         \
         }                                                                                               \
     }
-    // one step: RC holds this step's filters, RN receives those of step st_+2 (wrapping into the next chunk).
-    // Global loads are issued first and pinned above the MFMAs.
 #define STEP(st_, RC, RN)                                                                                \
     {                                                                                                   \
         if ((st_) + 2 < NST) { LOAD_R(RN, (st_) + 2, rec0) }                                            \

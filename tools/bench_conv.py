@@ -40,6 +40,9 @@ if what in ('conv', 'all'):
         a0 = torch.randn(n, h, w, c0, device='cuda').to(td)
         a1 = torch.randn(n, h, w, c1, device='cuda').to(td) if c1 else None
         wt = (torch.randn(co, 9, c0 + c1, device='cuda') * 0.05).to(td)
+        if os.environ.get('ZERO'):          # DVFS probe: all-zero operands draw less power -> higher clock (MI355X_MICROARCH.md)
+            a0.zero_(); wt.zero_()
+            if a1 is not None: a1.zero_()
         out = torch.empty(n, h, w, co, device='cuda', dtype=td)
         bn = torch.rand(2, 4, c0, device='cuda') + 0.5
         bias = torch.zeros(co, device='cuda')
