@@ -18,7 +18,8 @@ Extra objects on the same line:
   collectives    the same step with its five gradient-bucket all-reduces forced through RCCL (one rank), timed beside the local step;
   host_fed       the same step fed from pinned HOST memory through fabric_amd.input_pipeline.DeviceFeeder (PCIe inclusive);
   parity_setting pairs/s of the two float32-class settings (bf16x3: logits within 1e-3; fp32: exact f32 MFMA);
-  scene          BASELINE configs[4]: full-scene sliding-window inference of a 13-band 10000 x 10000 scene pair.
+  scene          BASELINE configs[4]: full-scene sliding-window inference of a 13-band 10000 x 10000 scene pair, resident in HBM and
+                 (scene.host_fed) streamed from pinned host memory under the compute.
 """
 import argparse
 import csv
@@ -295,7 +296,7 @@ def parity_leg(dev, B, C, S):
     return out
 
 
-def scene_leg(dev, size=10000, batch=256, reps=2):
+def scene_leg(dev, size=10000, batch=256, reps=2, band_rows=None):
     """BASELINE.json configs[4]: forward-only sliding-window inference of a 13-band size x size scene pair (6241 tiles at 10000:
     reference train.py:182-205 / utils/inference.py:134-236), scene planes resident in HBM as float32.  Tiles per forward batch: 256
     (the loop's `batch_size` is a free parameter of the reference; 64 -> 256 amortises the per-batch fixed cost: 32.9k -> 35.7k tiles/s)."""
@@ -325,7 +326,41 @@ def scene_leg(dev, size=10000, batch=256, reps=2):
                         'note': 'BASELINE calls the regime HBM-bound; with the scene resident and tiles gathered on the device the forward '
                                 'convolutions bound it (144 TFLOP vs 0.3 TB of ideal activation traffic)'},
            'hbm_algorithmic': {'bytes': act_bytes, 'GBps': act_bytes / best / 1e9, 'frac_of_peak': act_bytes / best / HBM_PEAK}}
-    del d1, d2, model
+    # the same scene fed from pinned HOST memory (the regime SURVEY n1 names: host -> device staging as long as the compute): the planes
+    # go up in 256-row bands on the copy stream while tiles of the bands that have arrived run (fabric_amd/utils/inference.py)
+    try:
+        h1 = torch.empty(13, size, size, dtype=torch.float32, pin_memory=True)
+        h2 = torch.empty(13, size, size, dtype=torch.float32, pin_memory=True)
+        h1.copy_(d1); h2.copy_(d2)
+        torch.cuda.synchronize()
+        del d1, d2
+        torch.cuda.empty_cache()
+        nbytes = 2 * h1.numel() * 4
+        tmp = torch.empty_like(h1, device=dev)                # a plain upload of one date into an existing buffer: the PCIe rate of this box
+        tmp.copy_(h1, non_blocking=True); torch.cuda.synchronize()
+        t = time.perf_counter()
+        tmp.copy_(h1, non_blocking=True); torch.cuda.synchronize()
+        pcie = h1.numel() * 4 / (time.perf_counter() - t)
+        del tmp
+        torch.cuda.empty_cache()
+        inf.predict_scene(model, h1, h2, 128, batch, band_rows=band_rows)
+        torch.cuda.synchronize()
+        fed = 1e9
+        for _ in range(reps):
+            t = time.perf_counter()
+            mask_h = inf.predict_scene(model, h1, h2, 128, batch, band_rows=band_rows)
+            torch.cuda.synchronize()
+            fed = min(fed, time.perf_counter() - t)
+        bound = max(best, nbytes / pcie)
+        out['host_fed'] = {'seconds': fed, 'tiles_per_s': n / fed, 'host_bytes': nbytes, 'pcie_GBps_plain_copy': pcie / 1e9,
+                           'pcie_GBps_sustained': nbytes / fed / 1e9, 'bound_seconds': bound, 'frac_of_bound': bound / fed,
+                           'mask_equals_resident': bool(torch.equal(mask_h, mask)),
+                           'how': 'pinned [13,H,W] float32 host planes -> 256-row bands on the copy stream, one event per band, tile batches wait '
+                                  'only for the last band they read; bound = max(resident compute time, bytes / plain-copy PCIe rate)'}
+        del h1, h2
+    except Exception as e:                                    # e.g. not enough pinnable host memory on the box
+        out['host_fed'] = {'error': f'{type(e).__name__}: {e}'}
+    del model
     torch.cuda.empty_cache()
     return out
 

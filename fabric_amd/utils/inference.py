@@ -115,11 +115,13 @@ def predict_patches(model, patches1, patches2, batch_size, device='cuda'):
 
 
 @torch.no_grad()
-def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shard=None, merge=True):
+def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shard=None, merge=True, band_rows=None):
     """Change mask of a whole scene.
 
     scene_d1, scene_d2: [C,H,W] float32 tensors (what the reference's city_loader returns per date,
-    utils/dataloaders.py:86-101); moved to the model's device if they are not there yet.
+    utils/dataloaders.py:86-101), resident on the model's device or in HOST memory.  Host scenes are streamed up in bands of
+    `band_rows` rows (default 256) on the copy stream while the tiles of the bands that have arrived run (pin the tensors:
+    pageable memory is staged through pinned buffers by host threads and is host-memcpy bound).
     Returns a uint8 [H,W] device tensor equal to ``_get_bands(argmax(model(tiles)))`` of the reference loop.
     shard=(rank, world): process only this rank's contiguous slice of the tile list; merge=True then combines
     the per-rank masks with one all-reduce(MAX) over the default process group (unwritten pixels are 0).
@@ -134,11 +136,10 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
     P = _eval_params(model)
     eng = model.engine()
     dev = next(model.parameters()).device
-    d1 = torch.as_tensor(scene_d1).to(device=dev, dtype=torch.float32).contiguous()
-    d2 = torch.as_tensor(scene_d2).to(device=dev, dtype=torch.float32).contiguous()
-    if d1.dim() != 3 or d1.shape != d2.shape:
-        raise RuntimeError(f'expected two [C,H,W] scenes of one shape, got {tuple(d1.shape)} and {tuple(d2.shape)}')
-    _, h, w = d1.shape
+    s1, s2 = torch.as_tensor(scene_d1), torch.as_tensor(scene_d2)
+    if s1.dim() != 3 or s1.shape != s2.shape:
+        raise RuntimeError(f'expected two [C,H,W] scenes of one shape, got {tuple(s1.shape)} and {tuple(s2.shape)}')
+    _, h, w = s1.shape
     o_np, _, _, _, _ = tile_origins(h, w, patch_size)
     n = len(o_np)
     lo, hi = 0, n
@@ -146,18 +147,105 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
         rank, world = shard
         per = -(-n // world)
         lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    feed = None
+    if s1.is_cuda and s2.is_cuda:
+        d1 = s1.to(device=dev, dtype=torch.float32).contiguous()
+        d2 = s2.to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        # scene in HOST memory (what the reference's city_loader returns): the planes go up in row bands on the copy stream while
+        # the tiles of the bands that have arrived are already being predicted -- the upload (10.4 GB at 10 000^2 x 13 x 2 dates,
+        # as long over PCIe as the whole forward takes) hides behind the compute instead of preceding it
+        feed = _SceneFeeder(s1.cpu(), s2.cpu(), dev, band_rows or max(patch_size, 256))
+        d1, d2 = feed.d1, feed.d2
     origins = torch.from_numpy(o_np).to(dev)
     mask = torch.zeros(h, w, dtype=torch.uint8, device=dev) if shard is not None \
         else torch.empty(h, w, dtype=torch.uint8, device=dev)
     seen = set()
     st = _lib.stream_ptr()
     for i in range(lo, hi, batch_size):
-        o = origins[i:min(hi, i + batch_size)]
+        j = min(hi, i + batch_size)
+        o = origins[i:j]
         nb = o.shape[0]
+        if feed is not None:
+            feed.need_rows(int(o_np[i:j, 0].max()) + patch_size)       # the current stream waits for the last band these tiles read
         logits, _ = eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen)
         seen.add(nb)
         call('bdn_argmax_stitch', ptr(logits), ptr(o), ptr(mask), nb, logits.shape[1], patch_size, h, w, st)
+    if feed is not None:
+        feed.close()
     if shard is not None and merge and shard[1] > 1:
         import torch.distributed as dist
         dist.all_reduce(mask, op=dist.ReduceOp.MAX)
     return mask
+
+
+class _SceneFeeder:
+    """Uploads two [C,H,W] float32 host scenes into device planes band by band (rows [k R, (k+1) R) of every plane of both
+    dates per band) on the process-wide copy stream, one event per band.  Pinned sources are DMA'd in place; pageable ones
+    are first copied into two alternating pinned band buffers by a few host threads (slower: the host memcpy, not PCIe, is
+    then the limit).  The reference copies every batch of host patches synchronously (train.py:194-197)."""
+
+    def __init__(self, s1, s2, dev, band_rows):
+        from concurrent.futures import ThreadPoolExecutor
+        from .. import streams
+        self.src = [s1.float().contiguous() if s1.dtype != torch.float32 or not s1.is_contiguous() else s1,
+                    s2.float().contiguous() if s2.dtype != torch.float32 or not s2.is_contiguous() else s2]
+        C, H, W = self.src[0].shape
+        self.R, self.H = band_rows, H
+        self.copy = streams.get('copy', dev)
+        self.cur = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self.copy):
+            # allocated UNDER the copy stream (see input_pipeline.py: a block of the consumer stream's pool may still be in use
+            # by kernels that stream has queued)
+            self.d1 = torch.empty(C, H, W, dtype=torch.float32, device=dev)
+            self.d2 = torch.empty(C, H, W, dtype=torch.float32, device=dev)
+        self.events, self.waited, self.issued = [], -1, 0
+        self.nbands = -(-H // band_rows)
+        self.pinned = all(t.is_pinned() for t in self.src)
+        self.pool = None if self.pinned else ThreadPoolExecutor(max_workers=8)
+        self.stage = None if self.pinned else [[torch.empty(C, min(band_rows, H), W, dtype=torch.float32, pin_memory=True)
+                                                 for _ in range(2)] for _ in range(2)]
+        self.stage_free = [None, None]                   # event after which a staging slot may be overwritten by the host
+        self.d1.record_stream(self.cur)
+        self.d2.record_stream(self.cur)
+        self._issue(self.LOOKAHEAD)
+
+    LOOKAHEAD = 4        # bands enqueued beyond the one a batch waits for: the copy stream never runs dry, the host never runs far ahead
+
+    def _issue(self, upto):
+        """Enqueue the uploads of bands [issued, upto]."""
+        C = self.src[0].shape[0]
+        while self.issued <= min(upto, self.nbands - 1):
+            k = self.issued
+            r0, r1 = k * self.R, min(self.H, (k + 1) * self.R)
+            if not self.pinned:
+                slot = k % 2
+                if self.stage_free[slot] is not None:
+                    self.stage_free[slot].synchronize()
+                jobs = [self.pool.submit(self.stage[d][slot][c, :r1 - r0].copy_, self.src[d][c, r0:r1]) for d in range(2) for c in range(C)]
+                for j in jobs:
+                    j.result()
+            with torch.cuda.stream(self.copy):
+                for d, dst in enumerate((self.d1, self.d2)):
+                    for c in range(C):                   # one contiguous [rows, W] block per plane
+                        src = self.src[d][c, r0:r1] if self.pinned else self.stage[d][k % 2][c, :r1 - r0]
+                        dst[c, r0:r1].copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy)
+            self.events.append(ev)
+            if not self.pinned:
+                self.stage_free[k % 2] = ev
+            self.issued += 1
+
+    def need_rows(self, rows):
+        """Make the consumer stream wait until scene rows [0, rows) have arrived (and keep the copy stream LOOKAHEAD bands ahead)."""
+        k = min(self.nbands - 1, (min(rows, self.H) - 1) // self.R)
+        self._issue(k + self.LOOKAHEAD)
+        if k > self.waited:
+            self.cur.wait_event(self.events[k])          # bands are uploaded in order on one stream: band k implies 0..k
+            self.waited = k
+
+    def close(self):
+        self.need_rows(self.H)
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)

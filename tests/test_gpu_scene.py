@@ -131,6 +131,27 @@ def test_predict_scene_matches_oracle(prec):
     assert np.array_equal(img.astype(np.uint8), inf.predict_scene(model, d1, d2, patch_size=p, batch_size=4).cpu().numpy())
 
 
+@pytest.mark.parametrize('pinned', [True, False])
+@pytest.mark.parametrize('band_rows', [8, 32, 50, 4096])
+def test_host_fed_scene_equals_resident_scene(pinned, band_rows):
+    """The scene in HOST memory (train.py:182-205's situation), uploaded band by band on the copy stream while tiles of the bands
+    that arrived are predicted: the mask is the resident scene's mask bit for bit -- bands thinner than a tile, a ragged last
+    band, one band for the whole scene; pinned sources (DMA in place) and pageable ones (staged through pinned buffers)."""
+    c, h, w, p = 13, 300, 260, 64
+    d1, d2 = _scene(c, h, w, 5)
+    model, _ = _calibrated_model(c, 'bf16', d1, d2, p)
+    t1, t2 = torch.from_numpy(d1), torch.from_numpy(d2)
+    ref = inf.predict_scene(model, t1.cuda(), t2.cuda(), patch_size=p, batch_size=6)
+    if pinned:
+        t1, t2 = t1.pin_memory(), t2.pin_memory()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # also from a non-default consumer stream
+        got = inf.predict_scene(model, t1, t2, patch_size=p, batch_size=6, band_rows=band_rows)
+    side.synchronize()
+    assert torch.equal(got, ref)
+    assert 0.02 < ref.float().mean().item() < 0.98
+
+
 def test_predict_scene_full_size_properties():
     """BASELINE config-5 shape at a bounded size (13 bands, 128-pixel tiles, 1000 x 900): the sharded scan equals
     the single scan, the scan is reproducible, and it equals the reference-style patch loop."""
