@@ -102,3 +102,110 @@ def to_ndhwc(x_ncdhw, cp, dtype):
     out = torch.zeros(n, d, h, w, cp, dtype=dtype, device=x_ncdhw.device)
     out[..., :c] = x_ncdhw.permute(0, 2, 3, 4, 1).to(dtype)
     return out
+
+
+class DoubleConv3d:
+    """(nn.Conv3d(ci, co, 3, padding=1) -> nn.BatchNorm3d(co) -> nn.ReLU) x 2 on [N, D, H, W, C] device tensors, forward and
+    backward, training-mode statistics: the 3-D counterpart of the reference's `double_conv` (models/unet_parts.py:8-23), i.e.
+    the block a 3D-UNet over the date axis would be made of (BASELINE configs[3]).  PARITY UNPINNED: the reference has no source
+    for such a model; tests/test_gpu_conv3d.py checks this block against the same stack of stock torch.nn modules.
+
+    Same fusion structure as the 2-D path: the convolutions emit per-tile BatchNorm statistics from their epilogue, relu(bn(z0))
+    is never materialised for the second convolution (applied while it stages its input), and because the D slices of a sample
+    are consecutive NHWC images every HBM-bound kernel of the 2-D path (BatchNorm finalize / backward, bdn_bnrelu) runs on these
+    tensors unchanged with N*D images.  Differences to the 2-D training step, by design of what exists: the weight-gradient GEMM
+    of the 3x3x3 convolution takes plain operands only, so backward materialises relu(bn(z0)) once (bdn_bnrelu), and the
+    BatchNorm backward uses the stand-alone three-kernel path (bdn_bn_bwd)."""
+
+    def __init__(self, cin, cout, precision='bf16', eps=1e-5, momentum=0.1, device='cuda'):
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if cout % 64:
+            raise RuntimeError(f'Cout={cout} must be a multiple of 64')
+        self.cin, self.cout, self.precision, self.eps, self.momentum = cin, cout, precision, eps, momentum
+        self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32
+        self.td = torch.bfloat16 if precision == 'bf16' else torch.float32
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise RuntimeError('fabric_amd: DoubleConv3d runs only on a ROCm device -- there is no CPU path')
+        f = lambda *s: torch.zeros(*s, device=dev)
+        # parameters / buffers under the names the torch.nn stack would give them (conv.0, bn 1, conv.3, bn 4)
+        self.P = {'conv.0.weight': f(cout, cin, 3, 3, 3), 'conv.0.bias': f(cout), 'conv.3.weight': f(cout, cout, 3, 3, 3), 'conv.3.bias': f(cout)}
+        for k in ('1', '4'):
+            self.P[f'conv.{k}.weight'] = torch.ones(cout, device=dev)
+            self.P[f'conv.{k}.bias'] = f(cout)
+            self.P[f'conv.{k}.running_mean'] = f(cout)
+            self.P[f'conv.{k}.running_var'] = torch.ones(cout, device=dev)
+            self.P[f'conv.{k}.num_batches_tracked'] = torch.zeros((), dtype=torch.int64, device=dev)
+        self._ops = None
+        self._saved = None
+
+    def load(self, state):
+        """Copy a state dict of the equivalent nn.Sequential(Conv3d, BatchNorm3d, ReLU, Conv3d, BatchNorm3d, ReLU)."""
+        for k, v in state.items():
+            self.P[k].copy_(v.to(self.P[k].device))
+        self._ops = None
+
+    def _convs(self):
+        if self._ops is None:
+            self._ops = (Conv3d3x3(self.P['conv.0.weight'], self.P['conv.0.bias'], self.precision),
+                         Conv3d3x3(self.P['conv.3.weight'], self.P['conv.3.bias'], self.precision))
+        return self._ops
+
+    def _finalize(self, part, key, count, dev):
+        lib = _lib.load()
+        rows, C = part.shape[0], self.cout
+        bn = torch.empty(1, 4, C, device=dev)
+        ws = torch.empty(max(lib.bdn_bn_finalize_workspace_bytes(rows, 1, C) // 8, 1), dtype=torch.float64, device=dev)
+        call('bdn_bn_finalize', ptr(part), rows, 1, C, count, ptr(self.P[f'conv.{key}.weight']), ptr(self.P[f'conv.{key}.bias']),
+             self.eps, self.momentum, ptr(self.P[f'conv.{key}.running_mean']), ptr(self.P[f'conv.{key}.running_var']),
+             ptr(self.P[f'conv.{key}.num_batches_tracked']), ptr(bn), ptr(ws), _lib.stream_ptr())
+        return bn
+
+    def forward(self, x):
+        """x: [N,D,H,W,cp] (cp = Cin rounded up to 16, channels >= Cin zero).  Returns relu(bn(conv(relu(bn(conv(x)))))) as
+        [N,D,H,W,Cout]; keeps what backward needs."""
+        op0, op1 = self._convs()
+        n, d, h, w, _ = x.shape
+        count = n * d * h * w
+        z0, part0 = op0.forward(x, stats=True)
+        bn0 = self._finalize(part0, '1', count, x.device)
+        z1, part1 = op1.forward(z0, in_bn=bn0, imgs_per_group=n, stats=True)
+        bn1 = self._finalize(part1, '4', count, x.device)
+        out = torch.empty_like(z1)
+        call('bdn_bnrelu', self.dt, ptr(z1), ptr(bn1), n * d, ptr(out), n * d, h, w, self.cout, _lib.stream_ptr())
+        self._saved = (x, z0, bn0, z1, bn1)
+        return out
+
+    def _bn_bwd(self, dA, z, bn, key, grads):
+        lib = _lib.load()
+        nd, h, w, C = z.shape[0] * z.shape[1], z.shape[2], z.shape[3], self.cout
+        ws = torch.empty(max(lib.bdn_bn_bwd_workspace_bytes(self.dt, nd, h, w, C, nd) // 4, 1), device=z.device)
+        sums = torch.empty(1, 2, C, device=z.device)
+        dz = torch.empty_like(z)
+        grads[f'conv.{key}.weight'] = torch.empty(C, device=z.device)
+        grads[f'conv.{key}.bias'] = torch.empty(C, device=z.device)
+        call('bdn_bn_bwd', self.dt, ptr(dA), C, ptr(z), ptr(bn), nd, nd, h, w, C, ptr(ws), ptr(sums),
+             ptr(grads[f'conv.{key}.weight']), ptr(grads[f'conv.{key}.bias']), ptr(dz), _lib.stream_ptr())
+        return dz
+
+    def backward(self, d_out):
+        """d_out: gradient wrt forward()'s output.  Returns (dx or None, grads) -- dx [N,D,H,W,cp] when the padded input width is
+        a multiple of 64 channels (a first layer with 13 bands has no data gradient), grads keyed like `P`."""
+        if self._saved is None:
+            raise RuntimeError('backward() needs a forward() first')
+        x, z0, bn0, z1, bn1 = self._saved
+        op0, op1 = self._convs()
+        n, d, h, w, _ = x.shape
+        grads = {}
+        dz1 = self._bn_bwd(d_out.contiguous(), z1, bn1, '4', grads)
+        a0 = torch.empty_like(z0)                              # the weight-gradient GEMM of the 3x3x3 convolution takes plain operands
+        call('bdn_bnrelu', self.dt, ptr(z0), ptr(bn0), n * d, ptr(a0), n * d, h, w, self.cout, _lib.stream_ptr())
+        grads['conv.3.weight'] = op1.wgrad(dz1, a0)
+        dA0 = op1.dgrad(dz1)
+        dz0 = self._bn_bwd(dA0, z0, bn0, '1', grads)
+        grads['conv.0.weight'] = op0.wgrad(dz0, x)
+        grads['conv.0.bias'] = torch.zeros(self.cout, device=x.device)      # a bias in front of a BatchNorm has no gradient
+        grads['conv.3.bias'] = torch.zeros(self.cout, device=x.device)
+        dx = op0.dgrad(dz0) if op0.wd is not None else None
+        return dx, grads
