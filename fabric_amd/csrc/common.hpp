@@ -96,21 +96,16 @@ __device__ __forceinline__ uint4 bnrelu_unit(const uint4& u, const float* sc, co
     for (int i = 0; i < N; i++) f[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
     return Unit<T>::pack(f);
 }
-// bf16: two channels per dword through the packed pipes -- v_pk_fma_f32, v_cvt_pk_bf16_f32, and the ReLU as a
-// signed 16-bit max with 0 on the rounded pair (a negative bf16 is a negative int16; rounding keeps the sign, so
-// round(max(x,0)) == max(round(x),0)).  6 VALU per dword instead of 9.
+// bf16: two channels per dword -- two scalar v_fma_f32 (NOT one v_pk_fma_f32: packed f32 math beside MFMAs costs the matrix
+// pipe, MI355X_MICROARCH.md; measured here: the BatchNorm-on-load convolutions +2-4 %, the weight-gradient staging +4 %), one
+// v_cvt_pk_bf16_f32, and the ReLU as a signed 16-bit max with 0 on the rounded pair (a negative bf16 is a negative int16;
+// rounding keeps the sign, so round(max(x,0)) == max(round(x),0)).
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
 __device__ __forceinline__ uint32_t bnrelu_pair(uint32_t u, float s0, float s1, float t0, float t1) {
-#ifdef BNRELU_SCALAR
     f32x2_t y;
     y.x = __builtin_fmaf(__uint_as_float(u << 16), s0, t0);
     y.y = __builtin_fmaf(__uint_as_float(u & 0xffff0000u), s1, t1);
     asm("" : "+v"(y.x)); asm("" : "+v"(y.y));                   // keep the SLP vectoriser from re-packing the two FMAs into v_pk_fma_f32
-#else
-    const f32x2_t z = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-    const f32x2_t s = {s0, s1}, t = {t0, t1};
-    const f32x2_t y = __builtin_elementwise_fma(z, s, t);
-#endif
     const bf16x2_t r = __builtin_convertvector(y, bf16x2_t);
     const s16x2_t zero = {0, 0};
     const s16x2_t q = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, r), zero);

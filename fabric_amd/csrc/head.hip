@@ -580,7 +580,17 @@ __global__ __launch_bounds__(1024) void tversky_finish_kernel(float* __restrict_
             sums[i] = a;
         }
     }
-    if (counts && tid < 4) { int v = 0; for (int b = 0; b < ncblk; b++) v += pcounts[b * 4 + tid]; counts[tid] = v; }
+    if (counts) {                                          // TP / FP / FN / correct counts: 256 block lanes x 4 counters, LDS tree (integers: any order)
+        int* ired = reinterpret_cast<int*>(lane_sums);
+        __syncthreads();                                   // lane_sums is free again
+        const int j = tid & 3, l = tid >> 2;
+        int v = 0;
+        for (int b = l; b < ncblk; b += 256) v += pcounts[b * 4 + j];
+        ired[tid] = v;
+        __syncthreads();
+        for (int s2 = 512; s2 >= 4; s2 >>= 1) { if (tid < s2) ired[tid] += ired[tid + s2]; __syncthreads(); }
+        if (tid < 4) counts[tid] = ired[tid];
+    }
     __syncthreads();
     double acc = 0.0;
     const int nc = ncls * W;

@@ -249,18 +249,6 @@ __device__ __forceinline__ u32x4_t gload16_asm(const void* sbase, unsigned voff)
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(sbase) : "memory");
     return r;
 }
-// scalar-FMA BatchNorm+ReLU of one 16-byte bf16 unit (packed f32 math beside another wave's MFMAs costs the matrix pipe)
-__device__ __forceinline__ uint32_t bnrelu_pair_s(uint32_t u, float s0, float s1, float t0, float t1) {
-    float y0 = __builtin_fmaf(__uint_as_float(u << 16), s0, t0);
-    float y1 = __builtin_fmaf(__uint_as_float(u & 0xffff0000u), s1, t1);
-    asm("" : "+v"(y0)); asm("" : "+v"(y1));                    // keep the SLP vectoriser from re-packing into v_pk_fma_f32
-    const f32x2_t y = {y0, y1};
-    const bf16x2_t r = __builtin_convertvector(y, bf16x2_t);
-    const s16x2_t zero = {0, 0};
-    const s16x2_t q = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, r), zero);
-    return __builtin_bit_cast(uint32_t, q);
-}
-
 template <bool USE_BN>
 __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
     constexpr int PW = Wg6::PW, STR = Wg6::STR, BUF = Wg6::BUF, PATCH_BYTES = Wg6::PATCH_BYTES;
@@ -382,8 +370,8 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
             _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
                 const u32x4_t r_ = P[i];                                                                \
                 const bool ok_ = ((M) >> i) & 1u;                                                       \
-                const unsigned b0_ = bnrelu_pair_s(r_.x, sc[0], sc[1], sh[0], sh[1]), b1_ = bnrelu_pair_s(r_.y, sc[2], sc[3], sh[2], sh[3]); \
-                const unsigned b2_ = bnrelu_pair_s(r_.z, sc[4], sc[5], sh[4], sh[5]), b3_ = bnrelu_pair_s(r_.w, sc[6], sc[7], sh[6], sh[7]); \
+                const unsigned b0_ = bnrelu_pair(r_.x, sc[0], sc[1], sh[0], sh[1]), b1_ = bnrelu_pair(r_.y, sc[2], sc[3], sh[2], sh[3]); \
+                const unsigned b2_ = bnrelu_pair(r_.z, sc[4], sc[5], sh[4], sh[5]), b3_ = bnrelu_pair(r_.w, sc[6], sc[7], sh[6], sh[7]); \
                 u32x4_t v_;                                                                             \
                 v_.x = ok_ ? b0_ : 0u; v_.y = ok_ ? b1_ : 0u; v_.z = ok_ ? b2_ : 0u; v_.w = ok_ ? b3_ : 0u; \
                 *reinterpret_cast<u32x4_t*>(smem + (wb_) + wbase + i * 32 * STR) = v_;                  \
