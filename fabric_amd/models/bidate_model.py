@@ -88,7 +88,8 @@ class BiDateNet(nn.Module):
         self.outc = outconv(64, n_classes)
 
         self.n_channels, self.n_classes = n_channels, n_classes
-        # 'bf16' = throughput setting, 'fp32' = 1e-3-parity setting
+        # 'bf16' = throughput setting; 'bf16x3' = float32 tensors with split bf16 GEMM operands (logits within 1e-3 of the reference at
+        # matrix-core speed); 'fp32' = exact f32 MFMA
         self.precision = precision or os.environ.get('BIDATE_PRECISION', 'bf16')
         self._engine = None
 
