@@ -16,6 +16,7 @@ Extra objects on the same line:
   cpu_baseline   the oracle's stock-torch assembly of the reference graph timed on the host cores (rank 0, N=1 only): median of 5
                  steps at B=16 and at B=4, at the fastest thread count;
   collectives    the same step with its five gradient-bucket all-reduces forced through RCCL (one rank), timed beside the local step;
+  mfma_ceiling   a bare MFMA loop on zero and on random bf16 operands: the data-dependent (power-bound) ceiling of the matrix cores;
   host_fed       the same step fed from pinned HOST memory through fabric_amd.input_pipeline.DeviceFeeder (PCIe inclusive);
   parity_setting pairs/s of the two float32-class settings (bf16x3: logits within 1e-3; fp32: exact f32 MFMA);
   scene          BASELINE configs[4]: full-scene sliding-window inference of a 13-band 10000 x 10000 scene pair, resident in HBM and
@@ -174,6 +175,30 @@ def rocprof_avg_us(kernel, precision):
         if r['Name'].startswith(key):
             return float(r['AverageNs']) / 1e3, os.path.relpath(path, ROOT)
     return None, os.path.relpath(path, ROOT)
+
+
+def mfma_ceiling():
+    """tools/probe_power_wall (built by __graft_entry__.build()): a bare v_mfma_f32_32x32x16_bf16 loop on every CU with all-zero and with
+    N(0,1) bf16 operands.  The chip clocks to its power budget, so the rate on random data -- not the data-sheet 2.5 PFLOP/s -- is what
+    any kernel can reach on real activations.  Returns None when the probe binary is absent."""
+    import subprocess
+    exe = os.path.join(ROOT, 'tools', 'probe_power_wall')
+    if not os.path.exists(exe):
+        return None
+    try:
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+        rows = {}
+        for line in txt.splitlines():
+            if 'TFLOP/s' in line:
+                name = line[:48].strip()
+                rows[name] = float(line.split('ms')[1].split('TFLOP/s')[0])
+        rnd = rows.get('N(0,1) random')
+        return {'unit': 'TFLOP/s', 'zero_operands': rows.get('all zero'), 'random_operands': rnd,
+                'frac_of_nominal_peak': None if rnd is None else rnd / (MFMA_BF16_PEAK / 1e12),
+                'how': 'bare v_mfma_f32_32x32x16_bf16 loop, one wave per SIMD on every CU, operands in registers (tools/probe_power_wall.hip): '
+                       'the chip clocks to its power budget, so random bf16 operands cap ANY kernel at this rate'}
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {e}'}
 
 
 # ---------------------------------------------------------------------------------------------- extra legs (rank 0, N = 1)
@@ -523,6 +548,11 @@ def main():
             out['hbm_frac'] = hb[0] / (ms_step * 1e-3) / HBM_PEAK
             out['hbm_source'] = hb[1] + ' (PMC FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of a step; bytes/step divided by this run\'s step time and 8 TB/s)'
         if world == 1 and not args.no_extras and args.precision == 'bf16':
+            mc = mfma_ceiling()
+            if mc is not None:
+                out['mfma_ceiling'] = mc
+                if mc.get('random_operands'):
+                    out['step_frac_of_mfma_ceiling'] = value * FLOP_PER_PAIR_FWD_BWD / (mc['random_operands'] * 1e12)
             if not args.force_collectives:
                 out['collectives'] = collectives_leg(ts, model, dev, x1, x2, lbl, args.steps)
             out['host_fed'] = host_fed_leg(ts, dev, B, C, S, args.steps, args.warmup, x1, x2, lbl)
