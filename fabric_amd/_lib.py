@@ -26,6 +26,10 @@ SIGNATURES = {
     'bdn_version': (_i, []),
     'bdn_stream_create': (_i, [_i, C.POINTER(C.c_void_p)]),
     'bdn_stream_destroy': (_i, [_vp]),
+    'bdn_event_create': (_i, [C.POINTER(C.c_void_p)]),
+    'bdn_event_destroy': (_i, [_vp]),
+    'bdn_event_record': (_i, [_vp, _vp]),
+    'bdn_stream_wait_event': (_i, [_vp, _vp]),
     'bdn_pack_input': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_pack_weights': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'bdn_pack_weights_multi': (_i, [_i, _vp, _i, _vp]),

@@ -194,6 +194,7 @@ class BiDateEngine:
         # tools/experimental/ the code).
         self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
+        self._handoffs = []             # reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
         self._prof_seen = 0
@@ -473,6 +474,19 @@ class BiDateEngine:
             call('bdn_conv3x3_wgrad_ex', *args, wg_flags(2, wk_, blk_), stp)
             self.prof.append((name, 2.0 * n * hk * wk * L.cout * 9 * (c0 + c1), e0, e1))
 
+        n_hand = [0]
+
+        def handoff(src, dst):
+            """Order what `dst` enqueues from now on behind what `src` has enqueued: a device-local event without the system-scope
+            fence of a default event (streams.HandOff; 6.213 -> 6.187 ms per step in one process), one reusable event per hand-off."""
+            if n_hand[0] == len(self._handoffs):
+                from .streams import HandOff
+                self._handoffs.append(HandOff())
+            ho = self._handoffs[n_hand[0]]
+            n_hand[0] += 1
+            ho.signal(src)
+            ho.wait(dst)
+
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
             if self._diag_skip_wgrad:                # tools/ab_step.py diagnostic only: how long is the dz chain alone?
                 return
@@ -484,9 +498,7 @@ class BiDateEngine:
                     grads[f'{L.conv}.bias'].zero_()
                 ready(keys)
                 return
-            ev = torch.cuda.Event()
-            ev.record(main)                          # dz, the BatchNorm gradients and everything before them
-            side.wait_event(ev)
+            handoff(main, side)                      # dz, the BatchNorm gradients and everything before them
             with torch.cuda.stream(side):
                 wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, side.cuda_stream)
                 if zero_bias_grads:
@@ -595,7 +607,7 @@ class BiDateEngine:
                     # this ready() may launch the LAST bucket's all-reduce, ordered behind the current (main) stream only;
                     # the bucket also holds e1b / e2a weight gradients whose GEMM + reduction are still queued on the side
                     # stream, so main joins side first (nothing of the chain is left to delay)
-                    main.wait_stream(side)
+                    handoff(side, main)
                 ready([f'{La.bn}.weight', f'{La.bn}.bias', f'{La.conv}.weight', f'{La.conv}.bias'])
                 keep += [dAb, dzb, dAa, dP]
                 dP = None
@@ -606,5 +618,5 @@ class BiDateEngine:
             keep += [dAb, dzb, dAa, dza, dP]
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
         if side is not None:
-            main.wait_stream(side)                   # every weight gradient is complete before the caller's next kernel
+            handoff(side, main)                      # every weight gradient is complete before the caller's next kernel
         return grads

@@ -44,3 +44,27 @@ def get(role, device=None):
                 _lib.call('bdn_stream_create', _ROLES[role], C.byref(h))
             s = _streams[key] = torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx))
         return s
+
+
+class HandOff:
+    """A reusable device-local event (bdn_event_create: no timing, no system-scope fence): `signal(src)` then `wait(dst)` orders
+    everything `dst` enqueues afterwards behind what `src` had enqueued.  Re-recording is safe: a wait captures the record that
+    preceded it."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _lib.call('bdn_event_create', C.byref(h))
+        self._h = h.value
+
+    def signal(self, src):
+        _lib.call('bdn_event_record', self._h, src.cuda_stream)
+
+    def wait(self, dst):
+        _lib.call('bdn_stream_wait_event', dst.cuda_stream, self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().bdn_event_destroy(self._h)
+        except Exception:
+            pass

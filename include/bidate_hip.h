@@ -44,6 +44,14 @@ int bdn_version(void);
  * The caller owns the stream and destroys it with bdn_stream_destroy. */
 int bdn_stream_create(int priority, void** stream_out);
 int bdn_stream_destroy(void* stream);
+/* Events for hand-offs between two streams of ONE device (the chain releases each layer's weight-gradient GEMM to the second stream):
+ * created with hipEventDisableTiming | hipEventDisableSystemFence -- a default event performs a system-scope release (cache write-back /
+ * invalidate towards the host) every time it is recorded.  Not for host-side synchronisation.  bdn_event_record(event, stream) and
+ * bdn_stream_wait_event(stream, event) enqueue and return. */
+int bdn_event_create(void** event_out);
+int bdn_event_destroy(void* event);
+int bdn_event_record(void* event, void* stream);
+int bdn_stream_wait_event(void* stream, void* event);
 
 /* ---- layout converters (boundary of BiDateNet.forward, models/bidate_model.py:22) ---- */
 /* x_d1, x_d2: [B,C,H,W] f32 NCHW  ->  out: [2B,H,W,Cpad] (date-1 images first), channels >= C zeroed. */
