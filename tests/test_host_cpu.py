@@ -234,3 +234,23 @@ def test_inference_tiler_matches_golden(golden_dir):
         assert np.array_equal(inf._get_bands(pred, *meta, patch_size=p), O.stitch_scene(pred, *metao, p))
     with pytest.raises(ValueError):
         inf.tile_origins(100, 300, 128)
+
+
+def test_streams_and_feeder_need_a_device():
+    """The product has no CPU path: asking for the step's streams (or a feeder) without a ROCm device fails loudly, and the
+    stream / event entry points validate their arguments before touching HIP."""
+    import torch
+    from fabric_amd import _lib, streams
+    with pytest.raises(ValueError):
+        streams.get('compute')
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            streams.get('chain')
+        from fabric_amd.input_pipeline import DeviceFeeder
+        with pytest.raises(RuntimeError):
+            DeviceFeeder('cpu')
+    for name, args, msg in (('bdn_stream_create', (0, None), 'null pointer'), ('bdn_stream_create', (7, None), 'null pointer'),
+                            ('bdn_stream_destroy', (None,), 'null pointer'), ('bdn_event_create', (None,), 'null pointer'),
+                            ('bdn_event_record', (None, None), 'null pointer'), ('bdn_stream_wait_event', (None, None), 'null pointer')):
+        with pytest.raises(RuntimeError, match=msg):
+            _lib.call(name, *args)
