@@ -3,7 +3,8 @@
 The reference runs everything on PyTorch's default stream (train.py:83-101).  Here a step uses
   'chain'  high priority: forward, loss, the dz chain of backward, SGD (fabric_amd/train_step.py);
   'wgrad'  the weight-gradient GEMMs and the gradient all-reduce buckets launched behind them (fabric_amd/engine.py);
-  'copy'   host -> device input copies (fabric_amd/input_pipeline.py, fabric_amd/utils/inference.py).
+  'copy'   host -> device input copies (fabric_amd/input_pipeline.py, fabric_amd/utils/inference.py); 'copy2' is a second one that only
+           the scene upload uses (one DMA engine per date).
 They must sit on three different hardware queues (two streams on one queue serialise: +8-14 % step time).  Round 2 took
 `torch.cuda.Stream()` per object, i.e. the NEXT stream of torch's pool each time, and some pool streams share a queue: the
 third TrainStep of a process was slower than the first.  Now the library creates each role's stream once
@@ -19,7 +20,7 @@ import torch
 
 from . import _lib
 
-_ROLES = {'chain': 1, 'wgrad': 0, 'copy': 0}        # role -> bdn_stream_create priority
+_ROLES = {'chain': 1, 'wgrad': 0, 'copy': 0, 'copy2': 0}        # role -> bdn_stream_create priority
 _streams = {}
 _lock = threading.Lock()
 
