@@ -775,6 +775,35 @@ def test_wgrad_kernel_variants_agree(mode):
         torch.cuda.synchronize()
         assert torch.equal(dw.cpu(), out[WG_ROLE])
 
+@pytest.mark.parametrize('shape', [(1, 8, 16, 64, 64, 1), (1, 9, 17, 64, 64, 1), (2, 8, 16, 128, 64, 1), (3, 24, 16, 64, 192, 3), (4, 16, 32, 64, 64, 2)])
+@pytest.mark.parametrize('bn', [False, True])
+def test_role_split_wgrad_on_tiny_problems(shape, bn):
+    """wgrad7's pipeline prologue / epilogue on problems of one to a few 128-pixel chunks per block (a block whose split holds a single
+    chunk still issues its two look-ahead fetches, all masked) and on odd chunk counts: same dW as the one-chunk-at-a-time kernel."""
+    from fabric_amd._lib import WG_ROLE, WG_SIMPLE, wg_flags
+    lib = _lib.load()
+    N, H, W, Cout, C0, ipg = shape
+    dt, td = DT['bf16']
+    dz = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 301)))
+    x0 = to_nhwc('bf16', rnd('bf16', _rand((N, C0, H, W), 302)))
+    bn_d = dev(bn_table(N // ipg, C0, 303)) if bn else None
+    mode = IN_BNRELU if bn else IN_PLAIN
+    out = {}
+    for v in (WG_SIMPLE, WG_ROLE):
+        for blocks in ((0, 1, 7) if v == WG_ROLE else (0,)):          # 1 block: one split holds every chunk; 7: odd chunk counts per split
+            fl = wg_flags(3, v, blocks)
+            assert lib.bdn_conv3x3_wgrad_variant(dt, N, H, W, Cout, C0, 0, ipg, mode, fl) == v
+            part = torch.empty(lib.bdn_wgrad_workspace_bytes_ex(dt, N, H, W, Cout, C0, 0, ipg, mode, fl) // 4, device='cuda')
+            dw = torch.full((Cout, C0, 3, 3), float('nan'), device='cuda')
+            _lib.call('bdn_conv3x3_wgrad_ex', dt, dz.data_ptr(), Cout, x0.data_ptr(), C0, None, 0, mode, bn_d.data_ptr() if bn else None, ipg,
+                      part.data_ptr(), dw.data_ptr(), C0, N, H, W, fl, st())
+            torch.cuda.synchronize()
+            out[(v, blocks)] = dw.cpu()
+            assert torch.isfinite(out[(v, blocks)]).all()
+    for blocks in (0, 1, 7):
+        assert_close(f'role-split ({blocks} blocks) vs simple', out[(WG_ROLE, blocks)], out[(WG_SIMPLE, 0)], 2e-6)
+
+
 # ------------------------------------------------------------------ bf16x3: float32 tensors, bf16 hi/lo split GEMM operands
 def _split_ref(t_nchw):
     """[N,C,H,W] f32 -> the [N,H,W,2C] bf16 operand bdn_split_pack must produce (hi | lo)."""
