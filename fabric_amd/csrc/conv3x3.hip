@@ -551,6 +551,7 @@ template <int CKB>
 static int dispatch_conv_x3(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
     if (g.TH == 16) return launch_conv<bf16s, CKB, 16, 16, 1, 64, 4, 1, false, float>(a, g.n_mtiles, st);
+    if (g.TI == 1 && p.BN == 128) return launch_conv<bf16s, CKB, 8, 16, 1, 128, 1, 4, false, float>(a, g.n_mtiles, st);   // wide layers: as the bf16 path
     if (g.TI == 1) return launch_conv<bf16s, CKB, 8, 16, 1, 64, 2, 2, false, float>(a, g.n_mtiles, st);
     return launch_conv<bf16s, CKB, 8, 8, 2, 64, 2, 2, false, float>(a, g.n_mtiles, st);
 }

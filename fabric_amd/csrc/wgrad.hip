@@ -27,7 +27,18 @@ struct WgradArgs {
     // dz of slice n pairs with the activation slice n + dshift, and chunks whose partner slice lies outside the sample are skipped
     // (8x16 tiles of one slice only).  Dz = 0: 2-D.
     int Dz, dshift;
+    // bf16x3 (the doubled-operand GEMM [dz_hi | dz_lo] x [a_hi | a_lo]): x3h > 0 = number of 64-wide co tiles of the hi half; the
+    // lo x lo quadrant (co tile >= x3h and ci tile >= n_cit / 2) contributes 2^-16 of the product and is neither computed nor read
+    int x3h, n_tiles;
 };
+
+// tile index -> (co tile, ci tile); with x3h the lo x lo quadrant is left out of the enumeration
+__device__ __forceinline__ void wg_tile(const WgradArgs& a, int tile, int& cot, int& cit) {
+    if (a.x3h == 0) { cot = tile / a.n_cit; cit = tile % a.n_cit; return; }
+    const int top = a.x3h * a.n_cit, hc = a.n_cit >> 1;
+    if (tile < top) { cot = tile / a.n_cit; cit = tile % a.n_cit; }
+    else { const int u = tile - top; cot = a.x3h + u / hc; cit = u % hc; }
+}
 
 template <typename T, int TH, int TW, int TI>
 struct WgCfg {
@@ -70,9 +81,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void wgrad_kernel(Wgra
     const int half = lane >> 5, l31 = lane & 31;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.n_cot * a.n_cit;
+    const int ntile = a.n_tiles;
     const int tile = logical % ntile, split = logical / ntile;
-    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
+    int cot_, cit_;
+    wg_tile(a, tile, cot_, cit_);
+    const int co0 = cot_ * 64, ci0 = cit_ * 64;
     const int Cin = a.C0 + a.C1;
 
     const T* src; int Csrc, cs; bool use_bn = false;
@@ -258,9 +271,11 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.n_cot * a.n_cit;
+    const int ntile = a.n_tiles;
     const int tile = logical % ntile, split = logical / ntile;
-    const int co0 = (tile / a.n_cit) * 64, ci0 = (tile % a.n_cit) * 64;
+    int cot_, cit_;
+    wg_tile(a, tile, cot_, cit_);
+    const int co0 = cot_ * 64, ci0 = cit_ * 64;
     const int Cin = a.C0 + a.C1;
     const int q_begin = split * a.per_split;
     const int q_end = min(a.n_mtiles, q_begin + a.per_split);
@@ -493,7 +508,7 @@ template <bool USE_BN>
 static int launch_wgrad7(const WgradArgs& a, hipStream_t st) {
     auto kern = wgrad7_kernel<USE_BN>;
     BDN_SET_SMEM_ONCE(kern, 3 * Wg6::BUF, "wgrad7");
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(512), 3 * Wg6::BUF, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_tiles), dim3(512), 3 * Wg6::BUF, st, a);
     BDN_CHECK_LAUNCH("wgrad7");
     return BDN_OK;
 }
@@ -738,7 +753,8 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 #ifndef WG_SIMPLE_MULT
 #define WG_SIMPLE_MULT 2
 #endif
-struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; int variant; };
+constexpr int WG_X3_SKIP = 1 << 30;          // internal plan flag, see wgrad_plan
+struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; int variant; int x3h, n_tiles; };
 static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {
     WgPlan p;
     const int Cin = C0 + C1;
@@ -746,7 +762,10 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
     p.n_cot = Cout / 64;
     p.n_cit = (Cin + 63) / 64;
     p.ksplit = Cin <= 32;
-    const int tiles = p.n_cot * p.n_cit;
+    // internal flag (bit 30, set by the bf16x3 entry on its doubled-operand call): leave the lo x lo quadrant out
+    p.x3h = ((flags >> 30) & 1) && p.n_cot % 2 == 0 && p.n_cit % 2 == 0 ? p.n_cot / 2 : 0;
+    const int tiles = p.n_cot * p.n_cit - (p.x3h ? p.x3h * (p.n_cit / 2) : 0);
+    p.n_tiles = tiles;
     // the pipelined kernels cover full 64-channel input tiles on 8x16 spatial tiles whose tensors stay below 2^31 elements
     const size_t cmax = (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1));
     const bool pipe_ok = dtype == BDN_BF16 && !p.ksplit && p.g.TI == 1 && C0 % 64 == 0 && C1 % 64 == 0 &&
@@ -772,7 +791,7 @@ extern "C" size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, i
                                                int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0 || imgs_per_group <= 0) return 0;
     if (dtype == BDN_BF16X3)      // doubled operands ([hi | lo] x [hi | lo]) through the bf16 plan + the [2 Cout][2 Cin][9] tile the quadrants are summed from
-        return bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags)
+        return bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags | WG_X3_SKIP)
                + (size_t)4 * Cout * (C0 + C1) * 9 * sizeof(float);
     const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags);
     return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * (C0 + C1) * sizeof(float);
@@ -795,7 +814,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     using CF = WgCfg<T, TH, TW, TI>;
     auto kern = wgrad_kernel<T, TH, TW, TI, KSPLIT>;
     BDN_SET_SMEM_ONCE(kern, CF::SMEM, "wgrad");
-    hipLaunchKernelGGL(kern, dim3(a.S * a.n_cot * a.n_cit), dim3(256), CF::SMEM, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_tiles), dim3(256), CF::SMEM, st, a);
     BDN_CHECK_LAUNCH("wgrad");
     return BDN_OK;
 }
@@ -816,10 +835,10 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
         if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "wgrad(bf16x3): one split-packed, plain operand");
         if (Cout <= 0 || Cout % 32 || C0 <= 0 || C0 % 8 || Cin_real <= 0 || Cin_real > C0)
             BDN_FAIL(BDN_E_SHAPE, "wgrad(bf16x3): Cout=%d must be a multiple of 32, C0=%d of 8, Cin_real=%d <= C0", Cout, C0, Cin_real);
-        const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * C0, 0, imgs_per_group, BDN_IN_PLAIN, phases);
+        const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * C0, 0, imgs_per_group, BDN_IN_PLAIN, phases | WG_X3_SKIP);
         float* tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(partial) + gemm_bytes);
         const int rc = bdn_conv3x3_wgrad_ex(BDN_BF16, dz, 2 * Cout, in0, 2 * C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group,
-                                            partial, tile, 2 * C0, N, H, W, phases, stream);
+                                            partial, tile, 2 * C0, N, H, W, phases | WG_X3_SKIP, stream);
         if (rc) return rc;
         if (phases & 2) return bdn_wgrad_x3_combine(tile, dw_oihw, Cout, C0, Cin_real, reinterpret_cast<hipStream_t>(stream));
         return BDN_OK;
@@ -840,7 +859,7 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr; a.imgs_per_group = imgs_per_group;
     a.partial = partial; a.N = N; a.H = H; a.W = W;
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles;
-    a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit;
+    a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.x3h = p.x3h; a.n_tiles = p.n_tiles;
     a.Dz = 0; a.dshift = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = BDN_OK;
@@ -925,7 +944,7 @@ extern "C" int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void*
     a.dz = dz; a.Cout = Cout; a.in0 = in; a.in1 = nullptr; a.C0 = C; a.C1 = 0; a.in_bn = nullptr; a.imgs_per_group = 1;
     a.partial = partial; a.N = NS; a.H = H; a.W = W;
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles;
-    a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit;
+    a.S = p.S; a.per_split = p.per_split; a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.x3h = 0; a.n_tiles = p.n_tiles;
     a.Dz = D;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int kd = 0; kd < 3; kd++) {

@@ -138,9 +138,10 @@ class Workspace:
         self.generation = 0        # bumped by every forward that overwrites the buffers (models/bidate_model.py checks it before a backward)
 
     def split_buf(self, which, numel):
-        """bf16x3: scratch for a split GEMM operand ([.., 2C] bf16 = hi | lo).  'a' activations and 'd' gradients on the chain's stream;
-        'wd' / 'w' / 'p' the weight-gradient GEMM's own dz / activation operands and workspace on its stream.  Grown on demand,
-        reused by every layer: each buffer is only ever touched by ONE stream, so in-order reuse is safe."""
+        """bf16x3: buffer of a split GEMM operand ([.., 2C] bf16 = hi | lo), grown on demand.  Keys: ('a', layer) the layer's input
+        operand, written by its training forward and read again by its weight-gradient GEMM; ('d', layer) its dz, split once on the
+        chain's stream for the data-gradient conv and the weight-gradient GEMM (per layer: the weight-gradient stream may lag a
+        layer behind); 'a' the shared operand buffer of eval forwards; 'p' the weight-gradient GEMM's workspace on its stream."""
         t = self._split.get(which)
         if t is None or t.numel() < numel:
             t = torch.empty(numel, dtype=torch.bfloat16, device=self.x0.device)
@@ -294,7 +295,8 @@ class BiDateEngine:
         z = ws.z[L.name]
         if self.x3:
             # the operand split does the cat and the BatchNorm+ReLU the f32 kernel would apply on load
-            sp = ws.split_buf('a', n * hk * wk * 2 * (c0 + c1))
+            # training: one buffer per layer, kept for the layer's weight-gradient GEMM (the same operand: no second split in backward)
+            sp = ws.split_buf(('a', L.name) if training else 'a', n * hk * wk * 2 * (c0 + c1))
             call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
             in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
         self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
@@ -437,10 +439,10 @@ class BiDateEngine:
             recorded on the stream it is launched on."""
             lib = _lib.load()
             if self.x3:
-                sd = ws.split_buf('wd', n * hk * wk * 2 * L.cout)        # own buffers: this runs on the weight-gradient stream, in order
-                sw = ws.split_buf('w', n * hk * wk * 2 * (c0 + c1))
-                call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sd), n, hk, wk, stp)
-                call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg, ptr(sw), n, hk, wk, stp)
+                # both operands were split already: the activations by this layer's forward, dz by split_dz() on the chain's stream
+                # (per-layer buffers: the weight-gradient stream may still read one while the chain splits the next layer's)
+                sd = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)
+                sw = ws.split_buf(('a', L.name), n * hk * wk * 2 * (c0 + c1))
                 nb = lib.bdn_wgrad_workspace_bytes_ex(BDN_BF16X3, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, 3)
                 part = ws.split_buf('p', nb // 2)
                 call('bdn_conv3x3_wgrad_ex', BDN_BF16X3, ptr(sd), L.cout, ptr(sw), c0 + c1, None, 0, IN_PLAIN, None, ipg,
@@ -487,7 +489,16 @@ class BiDateEngine:
             ho.signal(src)
             ho.wait(dst)
 
+        def split_dz(L, dz, n, ipg):
+            """bf16x3: the [hi | lo] split of layer L's dz, once, for its data-gradient conv AND its weight-gradient GEMM."""
+            hk, wk = ws.dims[L.level - 1]
+            sp = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)
+            call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sp), n, hk, wk, st)
+            return sp
+
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
+            if self.x3:
+                split_dz(L, dz, n, ipg)              # on the chain's stream, before the hand-off below
             if self._diag_skip_wgrad:                # tools/ab_step.py diagnostic only: how long is the dz chain alone?
                 return
             hk, wk = ws.dims[L.level - 1]
@@ -512,9 +523,7 @@ class BiDateEngine:
             _, wd = self._weights(L, P, True)
             out = e(n, hk, wk, L.cin)
             if self.x3:
-                sp = ws.split_buf('d', n * hk * wk * 2 * L.cout)
-                call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sp), n, hk, wk, st)
-                dz = sp
+                dz = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)     # written by split_dz() when this layer's wgrad was released
             if prev is None:
                 self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
                                  self.mdt, ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg,
