@@ -59,7 +59,8 @@ key = str(dev)
 
 def run(label, chain, side, blocks):
     step._hp = chain
-    eng._side[key] = side
+    from fabric_amd import streams as _streams
+    _streams._streams[(0, "wgrad")] = side          # fabric_amd/streams.py owns the step's streams since round 3
     eng.wgrad_blocks = blocks
     ts = []
     with torch.cuda.stream(chain):
