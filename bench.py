@@ -259,14 +259,13 @@ def collectives_leg(ts, model, dev, x1, x2, lbl, steps):
     nothing to exchange, so this prices the launches, the stream hand-offs and RCCL's own kernels beside two busy queues, not the
     xGMI transfer (53.6 MB per step; DESIGN.md section 5 prices that from the link rate).  Timed against the local step right
     before and after it in the same process."""
+    from fabric_amd.parallel import init_rccl
     from fabric_amd.train_step import TrainStep
     own_group = False
     try:
         if not dist.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', str(29000 + os.getpid() % 3000))
-            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+            init_rccl(0, 1, dev)
             own_group = True
         forced = TrainStep(model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, force_collectives=True)
         n = max(steps // 2, 10)
@@ -421,15 +420,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        from fabric_amd.parallel import init_rccl
+        init_rccl(rank, world, dev)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     if args.force_collectives and world == 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', str(29000 + os.getpid() % 3000))
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        from fabric_amd.parallel import init_rccl
+        init_rccl(0, 1, dev)
 
     from fabric_amd import BiDateNet
     from fabric_amd.train_step import TrainStep

@@ -22,6 +22,25 @@ import torch.distributed as dist
 import torch.utils.data
 
 
+def init_rccl(rank, world_size, device, high_priority=True):
+    """torch.distributed over RCCL ('nccl' IS RCCL on ROCm) for one process per GPU.  The collectives' internal stream is created
+    with HIGH priority: a bucket all-reduce is small (<= 19 MB) and sits on the path to the optimizer step, while the kernels it
+    shares the chip with -- the dz chain (also high priority) and the long-lived weight-gradient GEMM blocks -- would otherwise keep
+    RCCL's workgroups waiting for compute units until the end of backward."""
+    import os
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
+    kw = {}
+    if high_priority:
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw['pg_options'] = opts
+        except Exception:                                          # older / differently built torch: default priority
+            kw = {}
+    dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=torch.device(device), **kw)
+
+
 class FlatLayout:
     """Offsets of every parameter inside the flat parameter / gradient buffers."""
 

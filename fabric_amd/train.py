@@ -157,9 +157,8 @@ def main(argv=None):
     torch.cuda.set_device(dev)                            # the library's stream / workspace helpers follow the current device
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        from .parallel import init_rccl
+        init_rccl(rank, world, dev)
 
     import random
     random.seed(opt.seed)                                  # same dataset order / initial weights on every rank; augmentation draws
