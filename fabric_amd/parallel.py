@@ -22,11 +22,16 @@ import torch.distributed as dist
 import torch.utils.data
 
 
-def init_rccl(rank, world_size, device, high_priority=True):
-    """torch.distributed over RCCL ('nccl' IS RCCL on ROCm) for one process per GPU.  The collectives' internal stream is created
-    with HIGH priority: a bucket all-reduce is small (<= 19 MB) and sits on the path to the optimizer step, while the kernels it
-    shares the chip with -- the dz chain (also high priority) and the long-lived weight-gradient GEMM blocks -- would otherwise keep
-    RCCL's workgroups waiting for compute units until the end of backward."""
+def init_rccl(rank, world_size, device, high_priority=False):
+    """torch.distributed over RCCL ('nccl' IS RCCL on ROCm) for one process per GPU.
+
+    The collectives' internal stream keeps the DEFAULT priority.  A high-priority collective stream looks attractive (a bucket
+    all-reduce is small and on the path to the optimizer step) but HIP multiplexes streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and a collective stream that lands on the queue of the step's chain
+    stream serialises the two: measured with one rank and forced buckets, group created after the step's streams, the step took
+    +59 % with a high-priority collective stream (+1.0 % when the group was created first, +1.0 % with 8 hardware queues --
+    while the DEFAULT priority with 8 queues cost +16 %).  Default priority with the default queue count is the one
+    configuration that measured +1.0-1.2 % in both creation orders; bench.py reports the overhead it sees (`collectives`)."""
     import os
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC

@@ -125,7 +125,7 @@ os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 torch.cuda.set_device(0)
 from fabric_amd.parallel import init_rccl
-init_rccl(0, 1, torch.device('cuda', 0))          # the helper bench.py / train.py use: high-priority collective stream
+init_rccl(0, 1, torch.device('cuda', 0))          # the helper bench.py / train.py use
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep
 from oracle import filler
