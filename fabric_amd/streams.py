@@ -39,12 +39,78 @@ def get(role, device=None):
     with _lock:
         s = _streams.get(key)
         if s is None:
-            with torch.cuda.device(idx):
-                torch.cuda.current_stream()            # the device's context exists before the library asks HIP for a stream
-                h = C.c_void_p()
-                _lib.call('bdn_stream_create', _ROLES[role], C.byref(h))
-            s = _streams[key] = torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx))
+            s = _streams[key] = _create_distinct(idx, role)
         return s
+
+
+_graveyard = []          # streams that collided with another role's hardware queue: kept alive so that their queue slot stays taken
+
+
+def _create(idx, role):
+    with torch.cuda.device(idx):
+        torch.cuda.current_stream()                    # the device's context exists before the library asks HIP for a stream
+        h = C.c_void_p()
+        _lib.call('bdn_stream_create', _ROLES[role], C.byref(h))
+    s = torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx))
+    with torch.cuda.stream(s):                         # first use creates the hardware queue (milliseconds): do it now, not inside a probe
+        torch.zeros(1, device=s.device).add_(1.0)
+    s.synchronize()
+    return s
+
+
+def _create_distinct(idx, role, tries=6):
+    """A new stream for `role` that shares its hardware queue with none of the device's other role streams.  HIP multiplexes streams
+    onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority class in creation order (tools/probe_queues.py: the 5th and 6th
+    normal-priority streams of a process land on the queues of the 3rd and 4th), so a stream created late -- after the application, a
+    data loader or RCCL took theirs -- may be serialised with the chain or the weight-gradient stream.  Checked with `serialised`;
+    a colliding stream is parked (it keeps its slot) and another one is created."""
+    others = [v for (i, r), v in _streams.items() if i == idx]
+    s = _create(idx, role)
+    for _ in range(tries):
+        if not any(serialised(o, s) or serialised(s, o) for o in others):
+            return s
+        _graveyard.append(s)
+        s = _create(idx, role)
+    import warnings
+    warnings.warn(f'fabric_amd: no hardware queue of its own found for the {role!r} stream after {tries} tries: it shares one with another '
+                  f'stream of the training step, which will serialise them (GPU_MAX_HW_QUEUES={__import__("os").environ.get("GPU_MAX_HW_QUEUES", "4 (default)")})',
+                  RuntimeWarning)
+    return s
+
+
+def replace(role, device=None):
+    """Park the current stream of `role` and create a new one (used when the role's stream turned out to share a hardware queue with
+    a stream the library does not own, e.g. RCCL's collective stream: fabric_amd/parallel.py).  Objects that cached the old stream
+    must fetch it again."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _lock:
+        old = _streams.pop((idx, role), None)
+        if old is not None:
+            _graveyard.append(old)
+        s = _streams[(idx, role)] = _create_distinct(idx, role)
+        return s
+
+
+def serialised(a, b, sleep_cycles=6_000_000):
+    """Do streams `a` and `b` share a hardware queue?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    default); two streams on one queue run their kernels one after the other, which for the streams of the training step means
+    +8-60 % step time.  Probe: a ~3 ms sleep kernel on `a`, a tiny kernel on `b`; if `b`'s kernel completes only when `a`'s has,
+    they are serialised.  Synchronises the device; meant for setup time."""
+    dev = a.device
+    torch.cuda.synchronize(dev)
+    t = torch.zeros(64, device=dev)
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(sleep_cycles)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        t.add_(1.0)
+        eb.record(b)
+    eb.synchronize()
+    same = ea.query()                       # the sleep is already over when b's tiny kernel has finished: b waited behind it
+    torch.cuda.synchronize(dev)
+    return bool(same)
 
 
 class HandOff:

@@ -83,9 +83,8 @@ class TrainStep:
         every TrainStep shares it, so the N-th instance of a process is as fast as the first).  A training loop that makes it
         the current stream (``with torch.cuda.stream(step.stream()): ...``) saves the two cross-stream joins per step
         (~25 us of idle GPU)."""
-        if self._hp is None:
-            from . import streams
-            self._hp = streams.get('chain', device if device is not None else self.flat_params.device)
+        from . import streams
+        self._hp = streams.get('chain', device if device is not None else self.flat_params.device)      # not cached: streams.replace() may swap it
         return self._hp
 
     def _step(self, x_d1, x_d2, labels):
