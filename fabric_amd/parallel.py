@@ -26,12 +26,11 @@ def init_rccl(rank, world_size, device, high_priority=False):
     """torch.distributed over RCCL ('nccl' IS RCCL on ROCm) for one process per GPU.
 
     The collectives' internal stream keeps the DEFAULT priority.  A high-priority collective stream looks attractive (a bucket
-    all-reduce is small and on the path to the optimizer step) but HIP multiplexes streams onto a few hardware queues
-    (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and a collective stream that lands on the queue of the step's chain
-    stream serialises the two: measured with one rank and forced buckets, group created after the step's streams, the step took
-    +59 % with a high-priority collective stream (+1.0 % when the group was created first, +1.0 % with 8 hardware queues --
-    while the DEFAULT priority with 8 queues cost +16 %).  Default priority with the default queue count is the one
-    configuration that measured +1.0-1.2 % in both creation orders; bench.py reports the overhead it sees (`collectives`)."""
+    all-reduce is small and on the path to the optimizer step) but measured, with one rank and forced buckets, +48...+59 % step
+    time when the group is created after the step's streams (+1 % when created first, +0.4-1 % with GPU_MAX_HW_QUEUES=8 -- while
+    the DEFAULT priority with 8 queues cost +8...+16 %).  The mechanism is not established (a sleep-kernel probe does not find the
+    collective stream on the chain's hardware queue); default priority with the default queue count is the one configuration that
+    measured +1.0-1.2 % in both creation orders, and bench.py reports the overhead it sees (`collectives`)."""
     import os
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC
