@@ -201,6 +201,51 @@ def mfma_ceiling():
         return {'error': f'{type(e).__name__}: {e}'}
 
 
+# ---------------------------------------------------------------------------------------------- where the step's time goes
+_CLASS_OF = {'bdn_conv3x3_dgrad_bs': 'conv_dgrad', 'bdn_conv3x3_wgrad_ex': 'wgrad', 'bdn_conv3x3_wgrad_bnbwd': 'wgrad',
+             'bdn_bn_finalize': 'finalize', 'bdn_bn_bwd_finalize': 'finalize'}
+
+
+def step_classes(ts, x1, x2, lbl, B, dev):
+    """ONE instrumented, untimed step: every library call that takes a stream is bracketed by an event pair on that stream
+    (fabric_amd/_lib.py PROFILE), then summed per class and per queue.  Every pair is a small bubble and the two queues crowd into
+    each other's bubbles, so the sums run a few percent above an unprofiled step -- they say where a change landed, the headline says
+    how much it is worth.  conv_* and wgrad carry the algorithmic FLOP of their class, hbm_bound the committed PMC bytes."""
+    from fabric_amd import _lib, streams
+    torch.cuda.synchronize()
+    _lib.PROFILE = []
+    try:
+        ts.step(x1, x2, lbl)
+        torch.cuda.synchronize()
+        raw = _lib.PROFILE
+    finally:
+        _lib.PROFILE = None
+    chain, side = ts.stream().cuda_stream, streams.get('wgrad', dev).cuda_stream
+    cls, queues = {}, {'q0_chain': 0.0, 'q1_wgrad': 0.0, 'other': 0.0}
+    for name, phase, h, e0, e1 in raw:
+        c = _CLASS_OF.get(name) or (('conv_fwd' if phase == 'fwd' else 'conv_dgrad') if name == 'bdn_conv3x3' else 'hbm_bound')
+        ms = e0.elapsed_time(e1)
+        a = cls.setdefault(c, {'ms': 0.0, 'calls': 0})
+        a['ms'] += ms; a['calls'] += 1
+        queues['q0_chain' if h == chain else 'q1_wgrad' if h == side else 'other'] += ms
+    flop = {'conv_fwd': FLOP_PER_PAIR_FWD * B, 'conv_dgrad': (FLOP_PER_PAIR_FWD - 0.491e9) * B, 'wgrad': FLOP_PER_PAIR_FWD * B}
+    for c, f in flop.items():
+        if c in cls and cls[c]['ms'] > 0:
+            cls[c]['TFLOPs'] = f / cls[c]['ms'] / 1e9
+    tab, path = pmc_tables('bf16')
+    if tab and 'hbm_bound' in cls:
+        steps = tab['_meta']['steps']
+        nb = sum((v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch']) * v['launches'] for k, v in tab.items()
+                 if k != '_meta' and not k.startswith(('conv3x3', 'wgrad7', 'wgrad_kernel', 'wgrad_first', 'reduce_rows', 'bn_finalize', 'bn_bwd_finalize'))) / steps
+        cls['hbm_bound']['TBps'] = nb / cls['hbm_bound']['ms'] / 1e9
+        cls['hbm_bound']['bytes_source'] = os.path.relpath(path, ROOT)
+    for a in cls.values():
+        a['ms'] = round(a['ms'], 4)
+    return {'per_class': cls, 'queue_busy_ms': {k: round(v, 4) for k, v in queues.items() if v},
+            'how': 'one instrumented untimed step, an event pair around every library call on its own stream; wgrad = GEMM + its split-K '
+                   'reduction; finalize = the separately launched BatchNorm (backward) finalize calls; hbm_bound = everything else'}
+
+
 # ---------------------------------------------------------------------------------------------- extra legs (rank 0, N = 1)
 def _time_steps(ts, x1, x2, lbl, warm, n):
     for _ in range(warm):
@@ -389,6 +434,59 @@ def scene_leg(dev, size=10000, batch=256, reps=2, band_rows=None):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def visible_devices():
+    """GPUs this process could use.  BENCH_ASSUME_DEVICES overrides the probe (the CPU-only test of the launcher logic)."""
+    if os.environ.get('BENCH_ASSUME_DEVICES'):
+        return int(os.environ['BENCH_ASSUME_DEVICES'])
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def launch_plan(gpus, env, n_devices, argv):
+    """What `bench.py --gpus N` does, decided before anything touches a device:
+      ('run', None)      this process IS a rank (WORLD_SIZE == N, set by torch.distributed.run or by our own re-exec), or N == 1;
+      ('spawn', cmd)     no launcher above us and N > 1: re-exec under torch.distributed.run with N ranks on 127.0.0.1;
+      ('refuse', why)    fewer than N devices, or a launcher whose WORLD_SIZE differs from --gpus: a line whose n_gpus differs from
+                         --gpus is never printed (round-3 review: `python bench.py --gpus 8` silently ran one rank)."""
+    ws = env.get('WORLD_SIZE')
+    if gpus < 1:
+        return 'refuse', f'--gpus {gpus}'
+    if ws is not None:
+        if int(ws) != gpus:
+            return 'refuse', f'--gpus {gpus} but the launcher set WORLD_SIZE={ws}'
+        return 'run', None
+    if gpus == 1:
+        return 'run', None
+    if n_devices < gpus:
+        return 'refuse', f'--gpus {gpus} but only {n_devices} device(s) are visible'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return 'spawn', cmd
+
+
+def launcher_selftest(json_out):
+    """`--launcher-selftest`: every rank the launcher logic produced joins a gloo group on the CPU and rank 0 prints the contract's
+    keys with n_gpus = the number of ranks that really showed up (tests/test_host_cpu.py; no device is touched)."""
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        json_out.write(json.dumps({'metric': 'launcher-selftest', 'n_gpus': seen, 'world_size_env': world}) + '\n')
+        json_out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -404,7 +502,22 @@ def main():
     ap.add_argument('--scene-size', type=int, default=10000)
     ap.add_argument('--force-collectives', action='store_true',
                     help='N=1 only: the HEADLINE loop itself issues its gradient-bucket all-reduces through RCCL (world size 1)')
+    ap.add_argument('--windows', type=int, default=3,
+                    help='consecutive timed windows of --steps steps each; the headline is the MEDIAN window (all are reported)')
+    ap.add_argument('--launcher-selftest', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # --gpus N without a launcher above us: become the launcher (N ranks under torch.distributed.run), or refuse
+    what, detail = launch_plan(args.gpus, os.environ, visible_devices(), sys.argv[1:])
+    if what == 'refuse':
+        sys.stderr.write(f'bench.py: refusing to run: {detail}\n')
+        raise SystemExit(2)
+    if what == 'spawn':
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '8')
+        raise SystemExit(subprocess.run(detail, env=env).returncode)
 
     # the contract is ONE JSON line on stdout: keep a private handle on the real stdout for it and point file descriptor 1 at stderr
     # for everything else (RCCL prints a version banner through C stdio, which would otherwise land after the JSON line at exit)
@@ -412,6 +525,9 @@ def main():
     json_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
 
+    if args.launcher_selftest:
+        launcher_selftest(json_out)
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -422,7 +538,7 @@ def main():
     if world > 1:
         from fabric_amd.parallel import init_rccl
         init_rccl(rank, world, dev)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'      # launch_plan() refused anything else
     if args.force_collectives and world == 1:
         os.environ.setdefault('MASTER_PORT', str(29000 + os.getpid() % 3000))
         from fabric_amd.parallel import init_rccl
@@ -461,6 +577,14 @@ def main():
             a = conv_all.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
         eng.prof_filter = max(conv_all.items(), key=lambda kv: kv[1][2])[0]
+    classes = None
+    if not args.no_roofline and rank == 0:
+        try:
+            classes = step_classes(ts, x1, x2, lbl, B, dev)
+        except Exception as e:
+            classes = {'error': f'{type(e).__name__}: {e}'}
+    elif not args.no_roofline:
+        ts.step(x1, x2, lbl)                  # the other ranks run the same (uninstrumented) step: collectives stay matched
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -468,21 +592,34 @@ def main():
     if not args.no_roofline:
         eng.prof = []
     picks = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.prof_pick = i % n_dom if n_dom else None          # step i brackets the (i mod n)-th launch of the dominant kernel
-        picks.append(eng.prof_pick)
-        loss = ts.step(x1, x2, lbl)
-    enqueue_s = time.perf_counter() - t0                       # host time to enqueue K steps (no sync inside the loop)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # `--windows` consecutive windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced with
+    # MAX over the ranks; the headline is the MEDIAN window (all are reported), so that a 1-2 % change is resolvable from one record:
+    # value = steps * B * world / median window, ms_per_step * steps = that window.
+    windows, enqueue_s, k = [], 0.0, 0
+    for _ in range(max(1, args.windows)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            eng.prof_pick = k % n_dom if n_dom else None      # step k brackets the (k mod n)-th launch of the dominant kernel
+            picks.append(eng.prof_pick)
+            k += 1
+            loss = ts.step(x1, x2, lbl)
+        enq = time.perf_counter() - t0                         # host time to enqueue K steps (no sync inside the loop)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        w = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        windows.append(w)
+        enqueue_s += enq
+    enqueue_s /= len(windows)
+    elapsed = sorted(windows)[len(windows) // 2]
     prof, eng.prof, eng.prof_pick = eng.prof, None, None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     loss_val = float(loss.item())
     ms_step = elapsed / args.steps * 1e3
 
@@ -527,7 +664,9 @@ def main():
         out = {
             'metric': 'patch-pairs/sec (fwd+bwd) 13-band 128x128', 'value': value, 'unit': 'patch-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': ms_step, 'windows_ms_per_step': [w / args.steps * 1e3 for w in windows],
+            'timing': f'median of {len(windows)} consecutive windows of {args.steps} steps (barrier + synchronize around each, max over ranks)',
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'BiDateNet({C},2) {C}-band {S}x{S} patch pairs, batch {B}/GPU, '
                                    f'fwd + Tversky + bwd + grad all-reduce + SGD (BASELINE configs[{1 if world == 1 else 2}])',
@@ -538,6 +677,7 @@ def main():
             'final_loss': loss_val,
             'host_enqueue_ms_per_step': enqueue_s / args.steps * 1e3,
             'roofline': roofline,
+            'step_classes': classes,
         }
         hb = pmc_step_bytes(args.precision)
         if hb is not None:

@@ -108,10 +108,34 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# Per-call timing for bench.py's instrumented step (measurement only): when PROFILE is a list, every entry point that takes a
+# stream (always its last argument) is bracketed by an event pair on that stream and (name, PHASE, stream, e0, e1) is appended.
+PROFILE = None
+PHASE = ''            # 'fwd' / 'bwd': set by the engine, lets the profile tell a data-gradient conv from a forward conv
+_ext_streams = {}
+
+
+def _profiled(lib, name, args):
+    import torch
+    h = args[-1] or 0
+    st = _ext_streams.get(h)
+    if st is None:
+        st = _ext_streams[h] = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    rc = getattr(lib, name)(*args)
+    e1.record(st)
+    PROFILE.append((name, PHASE, h, e0, e1))
+    return rc
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; raise RuntimeError with the library's message on failure."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is _vp and not name.startswith(('bdn_stream', 'bdn_event')):
+        rc = _profiled(lib, name, args)
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.bdn_last_error().decode(errors='replace')
         raise RuntimeError(f'{name} failed (rc={rc}): {msg}')

@@ -360,6 +360,7 @@ class BiDateEngine:
         B, H, W = ws.B, ws.H, ws.W
         dev = ws.x0.device
         st = _lib.stream_ptr()
+        _lib.PHASE = 'fwd'
         by = {L.name: L for L in self.layers}
         if self._packed_valid and (self._packed_versions != tuple(P[f'{L.conv}.weight']._version for L in self.layers) or
                                    self._pack_desc[0] != tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)):
@@ -412,6 +413,7 @@ class BiDateEngine:
         dev = dlogits.device
         dlogits = dlogits.contiguous().float()
         st = _lib.stream_ptr()
+        _lib.PHASE = 'bwd'
         by = {L.name: L for L in self.layers}
         sc = ws.bwd_scratch(dev)
         td, es = self.tdtype, self.esize

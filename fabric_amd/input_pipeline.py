@@ -32,11 +32,15 @@ class DeviceFeeder:
             raise RuntimeError('fabric_amd: DeviceFeeder needs a ROCm device')
         self.device = torch.device(device)
         self.depth = max(2, depth)       # 3: a slot is refilled two steps after it was read (2 slots: +7.5 % step time, 3: +2.5 %)
-        from . import streams
-        self.copy_stream = streams.get('copy', self.device)      # process-wide: a feeder per epoch does not grow the stream count
         self.slots = [_Slot() for _ in range(self.depth)]
         self.pool = ThreadPoolExecutor(max_workers=stage_threads) if stage_threads > 1 else None
         self.stage_threads = stage_threads
+
+    @property
+    def copy_stream(self):
+        """The process-wide copy stream of the device, fetched on every use (streams.replace() may have swapped it)."""
+        from . import streams
+        return streams.get('copy', self.device)
 
     def close(self):
         """Stop the staging threads and drop the device slots / pinned buffers (the copy stream is process-wide and stays)."""
@@ -73,9 +77,10 @@ class DeviceFeeder:
     def _issue(self, slot, batch):
         batch = [torch.as_tensor(t) for t in batch]
         src = self._pinned(slot, batch)
+        cs = self.copy_stream
         if slot.free is not None:
-            self.copy_stream.wait_event(slot.free)       # the step that read this slot last is done with it
-        with torch.cuda.stream(self.copy_stream):
+            cs.wait_event(slot.free)                     # the step that read this slot last is done with it
+        with torch.cuda.stream(cs):
             if slot.dev is None or any(d.shape != t.shape or d.dtype != t.dtype for d, t in zip(slot.dev, src)):
                 # allocated UNDER the copy stream: a block handed out by the consumer stream's pool may still be in use by kernels
                 # that stream has queued (its temporaries are freed on the host long before they are dead on the device), and
@@ -83,7 +88,7 @@ class DeviceFeeder:
                 slot.dev = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in src]
             for d, t in zip(slot.dev, src):
                 d.copy_(t, non_blocking=True)
-            slot.ready.record(self.copy_stream)
+            slot.ready.record(cs)
         slot.issued = True
 
     # ------------------------------------------------------------------ iteration

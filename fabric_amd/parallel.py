@@ -85,6 +85,8 @@ class GradBucketer:
         self.enabled = enabled                      # False: purely local step even inside an initialised process group
         self.force = force                          # True: issue the bucket all-reduces even in a world of one rank (a way to run the
                                                     # RCCL launches, their stream ordering and their cost on a single GPU)
+        self.defer = False                          # True: no launches from inside backward; finish() issues every bucket from the
+                                                    # caller's stream (TrainStep.guard_collectives' last remedy)
         skip = set(keys_no_reduce)
         keys = [k for k in layout.order if k not in skip]
         assert keys == layout.order[:len(keys)], 'non-reduced gradients must form the tail of the layout'
@@ -138,7 +140,7 @@ class GradBucketer:
 
     def on_ready(self, keys):
         """Backward hook: `keys` have just been enqueued on the current stream."""
-        if not self.active():
+        if not self.active() or self.defer:
             return
         for k in keys:
             i = self.key_bucket.get(k)

@@ -44,6 +44,31 @@ def get(role, device=None):
 
 
 _graveyard = []          # streams that collided with another role's hardware queue: kept alive so that their queue slot stays taken
+_GRAVEYARD_CAP = 16      # parked streams per process; beyond that the oldest is destroyed (its slot is long since behind newer streams)
+
+
+def _park(s):
+    _graveyard.append(s)
+    while len(_graveyard) > _GRAVEYARD_CAP:
+        _destroy(_graveyard.pop(0))
+
+
+def _destroy(s):
+    try:
+        s.synchronize()
+        _lib.load().bdn_stream_destroy(s.cuda_stream)
+    except Exception:
+        pass
+
+
+def _bury_all():
+    """atexit: parked streams are destroyed (the role streams in use stay with the process until the HIP runtime tears down)."""
+    while _graveyard:
+        _destroy(_graveyard.pop())
+
+
+import atexit
+atexit.register(_bury_all)
 
 
 def _create(idx, role):
@@ -61,15 +86,17 @@ def _create(idx, role):
 def _create_distinct(idx, role, tries=6):
     """A new stream for `role` that shares its hardware queue with none of the device's other role streams.  HIP multiplexes streams
     onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority class in creation order (tools/probe_queues.py: the 5th and 6th
-    normal-priority streams of a process land on the queues of the 3rd and 4th), so a stream created late -- after the application, a
-    data loader or RCCL took theirs -- may be serialised with the chain or the weight-gradient stream.  Checked with `serialised`;
-    a colliding stream is parked (it keeps its slot) and another one is created."""
-    others = [v for (i, r), v in _streams.items() if i == idx]
+    normal-priority streams of a process land on the queues of the 3rd and 4th), so a stream created late may be serialised with the
+    chain or the weight-gradient stream.  Checked with `serialised` against the library's OTHER role streams of the device and torch's
+    default stream; a colliding stream is parked (it keeps its slot) and another one is created.  Streams the library cannot see -- a
+    data loader's, RCCL's collective stream -- are not probed here: TrainStep.guard_collectives measures their effect on the step
+    instead and calls replace() when it finds one."""
+    others = [v for (i, r), v in _streams.items() if i == idx and r != role] + [torch.cuda.default_stream(idx)]
     s = _create(idx, role)
     for _ in range(tries):
         if not any(serialised(o, s) or serialised(s, o) for o in others):
             return s
-        _graveyard.append(s)
+        _park(s)
         s = _create(idx, role)
     import warnings
     warnings.warn(f'fabric_amd: no hardware queue of its own found for the {role!r} stream after {tries} tries: it shares one with another '
@@ -79,15 +106,15 @@ def _create_distinct(idx, role, tries=6):
 
 
 def replace(role, device=None):
-    """Park the current stream of `role` and create a new one (used when the role's stream turned out to share a hardware queue with
-    a stream the library does not own, e.g. RCCL's collective stream: fabric_amd/parallel.py).  Objects that cached the old stream
-    must fetch it again."""
+    """Park the current stream of `role` and create a new one (TrainStep.guard_collectives: the role's stream turned out to be slowed
+    down by a stream the library does not own, e.g. RCCL's collective stream).  Nothing in the library caches a role stream across
+    calls (engines, TrainStep.stream() and the feeders fetch it on every use); work already queued on the parked stream completes."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     with _lock:
         old = _streams.pop((idx, role), None)
         if old is not None:
-            _graveyard.append(old)
+            _park(old)
         s = _streams[(idx, role)] = _create_distinct(idx, role)
         return s
 

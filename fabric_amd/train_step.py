@@ -20,8 +20,13 @@ from .parallel import FlatLayout, GradBucketer
 
 class TrainStep:
     def __init__(self, model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, eps=1e-7,
-                 process_group=None, n_buckets=4, distributed=True, force_collectives=False):
+                 process_group=None, n_buckets=4, distributed=True, force_collectives=False, guard=True):
+        """guard: when the step issues collectives (world > 1, or force_collectives), the first step() first runs
+        guard_collectives() -- a few timed steps with and without the bucket all-reduces -- and repairs / reports a stream
+        arrangement in which they slow the step down (see there)."""
         self.model, self.lr = model, lr
+        self._guard = guard
+        self.collectives_report = None
         self.alpha, self.beta, self.eps = tversky_alpha, tversky_beta, eps
         self.group = process_group
         self.high_priority_chain = True
@@ -64,6 +69,8 @@ class TrainStep:
         weight-gradient GEMMs run beside it on a normal-priority stream (engine.backward), so the chain's kernels get
         compute units first (A/B tools/ab_prio.py: -0.8 % step time).  The caller's current stream is joined on both
         sides, so the usual stream semantics hold for inputs and outputs."""
+        if self._guard and self.collectives_report is None and self.bucketer.active():
+            self.guard_collectives(*[int(v) for v in (x_d1.shape[0], x_d1.shape[2], x_d1.shape[3])])
         if not self.high_priority_chain:
             return self._step(x_d1, x_d2, labels)
         cur = torch.cuda.current_stream(x_d1.device)
@@ -86,6 +93,103 @@ class TrainStep:
         from . import streams
         self._hp = streams.get('chain', device if device is not None else self.flat_params.device)      # not cached: streams.replace() may swap it
         return self._hp
+
+    # ------------------------------------------------------------------ run-time guard for the collectives' stream placement
+    def _time_steps(self, x1, x2, lbl, n, warm):
+        import time
+        dev = x1.device
+        with torch.cuda.stream(self.stream(dev)):
+            for _ in range(warm):
+                self._step(x1, x2, lbl)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                self._step(x1, x2, lbl)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / n
+
+    def guard_collectives(self, B, H, W, steps=8, threshold=0.05, verbose=False):
+        """Is the step slowed down by WHERE its collectives run?  RCCL's collective stream is created by torch, not by this library,
+        and its hardware-queue placement relative to the chain / weight-gradient streams depends on creation order, priority and
+        GPU_MAX_HW_QUEUES: one combination measured +48...+59 % step time, invisible to a sleep-kernel probe.
+        So it is MEASURED: `steps` steps on synthetic inputs of the run's shape with the bucket all-reduces and without; while the
+        overhead exceeds `threshold` the remedies are tried in order and kept only if they help --
+          1. a new weight-gradient stream (streams.replace: the old one is parked so that its queue slot stays taken),
+          2. a new chain stream,
+          3. the buckets launched from the CHAIN's stream at the end of backward (bucketer.defer: no overlap with backward any more,
+             but no interference either -- costs the exposed transfer instead of half a step);
+        and a RuntimeWarning says so when none of them brings it under the threshold.  With several ranks the decision is taken on the
+        MAX over ranks, so every rank walks the same path.  Parameters, BatchNorm buffers and the bucketer state are restored:
+        the model is exactly as before.  Returns (and keeps in `collectives_report`) what was measured."""
+        import warnings
+        from . import streams
+        dev = self.flat_params.device
+        if not self.bucketer.active():
+            self.collectives_report = {'active': False}
+            return self.collectives_report
+        backend = str(dist.get_backend(self.group))
+        if 'nccl' not in backend:                                       # gloo (tests on one GPU / CPU): reductions run on the host, no collective stream
+            self.collectives_report = {'active': True, 'guarded': False, 'reason': f'backend {backend}: no device-side collective stream'}
+            return self.collectives_report
+        self.collectives_report = {'running': True}                     # re-entrancy: _step below must not call the guard again
+        g = torch.Generator(device='cpu').manual_seed(99)
+        C = self.model.n_channels
+        x1 = torch.randn(B, C, H, W, generator=g).to(dev)
+        x2 = (x1 + 0.3 * torch.randn(B, C, H, W, generator=g).to(dev))
+        lbl = (torch.rand(B, H, W, generator=g) < 0.1).to(torch.uint8).to(dev)
+        saved = {k: v.clone() for k, v in self._P.items()}
+        saved_flat = self.flat_params.clone()
+        eng = self.model.engine()
+
+        def overhead():
+            self.bucketer.enabled = False
+            t_local = self._time_steps(x1, x2, lbl, steps, 3)
+            self.bucketer.enabled = True
+            t_coll = self._time_steps(x1, x2, lbl, steps, 3)
+            t = torch.tensor([t_local, t_coll], dtype=torch.float64, device=dev)
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            t_local, t_coll = float(t[0]), float(t[1])
+            return t_coll / t_local - 1.0, t_local, t_coll
+
+        tried = []
+        try:
+            ov, tl, tc = overhead()
+            tried.append({'remedy': 'none', 'overhead_frac': ov, 'local_ms': tl * 1e3, 'collectives_ms': tc * 1e3})
+            best = ov
+            for remedy in ('new_wgrad_stream', 'new_chain_stream', 'deferred_buckets'):
+                if best <= threshold:
+                    break
+                if remedy == 'new_wgrad_stream':
+                    streams.replace('wgrad', dev)
+                elif remedy == 'new_chain_stream':
+                    streams.replace('chain', dev)
+                else:
+                    self.bucketer.defer = True
+                ov, tl, tc = overhead()
+                tried.append({'remedy': remedy, 'overhead_frac': ov, 'local_ms': tl * 1e3, 'collectives_ms': tc * 1e3})
+                if remedy == 'deferred_buckets' and ov >= best:
+                    self.bucketer.defer = False                        # did not help: keep the overlapped launches
+                best = min(best, ov)
+                if verbose:
+                    print(f'guard_collectives: {remedy}: overhead {ov * 100:+.1f} %', flush=True)
+        finally:
+            self.bucketer.enabled = True
+            self.bucketer.reset()
+            for k, v in saved.items():
+                self._P[k].copy_(v)
+            self.flat_params.copy_(saved_flat)
+            eng.invalidate_weights()
+            torch.cuda.synchronize(dev)
+        rep = {'active': True, 'threshold': threshold, 'steps': steps, 'world': self.world, 'tried': tried,
+               'overhead_frac': tried[-1]['overhead_frac'] if tried else None, 'deferred_buckets': bool(self.bucketer.defer),
+               'recovered': len(tried) > 1 and best <= threshold, 'ok': best <= threshold}
+        if best > threshold:
+            warnings.warn(f'fabric_amd: the gradient all-reduces cost the step {best * 100:+.0f} % (threshold {threshold * 100:.0f} %) and no '
+                          f'stream re-arrangement brought that down: {tried}.  Try creating the process group BEFORE the first TrainStep, the '
+                          f'default (not high) collective-stream priority, and the default GPU_MAX_HW_QUEUES.', RuntimeWarning)
+        self.collectives_report = rep
+        return rep
 
     def _step(self, x_d1, x_d2, labels):
         model = self.model

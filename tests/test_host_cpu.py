@@ -254,3 +254,30 @@ def test_streams_and_feeder_need_a_device():
                             ('bdn_event_record', (None, None), 'null pointer'), ('bdn_stream_wait_event', (None, None), 'null pointer')):
         with pytest.raises(RuntimeError, match=msg):
             _lib.call(name, *args)
+
+
+def test_bench_launches_its_own_ranks_or_refuses():
+    """`python bench.py --gpus N` without a launcher above it must become N ranks (torch.distributed.run on 127.0.0.1) or refuse with
+    a non-zero exit -- never print a line whose n_gpus differs from --gpus (round-3 review: it silently ran ONE rank).  The launcher
+    logic runs for real here with the compute replaced by a gloo head count on the CPU (--launcher-selftest)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ['--gpus', '2', '--steps', '3']
+    assert bench.launch_plan(1, {}, 0, argv) == ('run', None)
+    assert bench.launch_plan(2, {'WORLD_SIZE': '2'}, 0, argv) == ('run', None)            # we ARE a rank of a 2-rank launch
+    assert bench.launch_plan(8, {'WORLD_SIZE': '1'}, 8, argv)[0] == 'refuse'               # a launcher that disagrees with --gpus
+    assert bench.launch_plan(8, {}, 1, argv)[0] == 'refuse'                                # one visible device, eight asked for
+    what, cmd = bench.launch_plan(2, {}, 2, argv)
+    assert what == 'spawn' and '--nproc-per-node=2' in cmd and '127.0.0.1' in cmd and cmd[-len(argv):] == argv
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['BENCH_ASSUME_DEVICES'] = '2'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher-selftest'],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['world_size_env'] == 2, r.stdout
+    # no launcher and too few devices (this container has none): refusal, exit code 2, nothing on stdout
+    env.pop('BENCH_ASSUME_DEVICES')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 2 and 'refusing' in r.stderr and not r.stdout.strip()
