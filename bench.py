@@ -321,6 +321,7 @@ def collectives_leg(ts, model, dev, x1, x2, lbl, steps):
         sizes = [(hi - lo) * 4 for lo, hi, _ in forced.bucketer.buckets]
         out = {'ms_per_step': f, 'local_ms_per_step_adjacent': local, 'overhead_frac': f / local - 1.0,
                'buckets': len(sizes), 'bucket_bytes': sizes, 'backend': 'nccl (RCCL), world size 1, all-reduces forced',
+               'guard': forced.collectives_report,
                'what_it_prices': 'launch + stream ordering + RCCL kernels beside the two busy queues; NOT the xGMI transfer'}
         del forced
         return out
@@ -557,6 +558,11 @@ def main():
     lbl = (torch.rand(B, S, S, generator=g) < 0.1).to(torch.uint8)
     x1, x2, lbl = x1.to(dev), x2.to(dev), lbl.to(dev)     # resident in HBM before the timed region
 
+    guard = None
+    if world > 1 or args.force_collectives:
+        # measure the collectives' cost on THIS stream arrangement before anything is timed, and repair it if it is the slow one
+        # (TrainStep.guard_collectives: may replace the chain / weight-gradient stream, so it runs before the loop adopts the chain's)
+        guard = ts.guard_collectives(B, S, S)
     torch.cuda.synchronize()
     torch.cuda.set_stream(ts.stream())       # the loop runs on the step's own high-priority stream, as fabric_amd/train.py's does:
                                              # no cross-stream joins at the step boundaries (~25 us of idle GPU per step)
@@ -679,6 +685,10 @@ def main():
             'roofline': roofline,
             'step_classes': classes,
         }
+        if guard is not None:
+            out['collectives'] = {'overhead_frac': guard.get('overhead_frac'), 'guard': guard,
+                                  'what_it_prices': 'the step with its bucket all-reduces vs the same step without them, measured on synthetic '
+                                                    'inputs before the timed region (max over ranks); with N > 1 this includes the xGMI transfer'}
         hb = pmc_step_bytes(args.precision)
         if hb is not None:
             out['hbm_bytes_per_step'] = hb[0]

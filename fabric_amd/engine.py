@@ -148,6 +148,11 @@ class Workspace:
             self._split[which] = t
         return t[:numel]
 
+    def release_split(self):
+        """bf16x3: drop the per-layer operand-split buffers (at B=16, 128x128 about 1.5 GB per workspace that has trained).  They are
+        re-grown on demand by the next training forward; an eval-only phase after training calls this (BiDateNet.eval() does)."""
+        self._split = {}
+
     def outc_ws(self, eng):
         """Scratch of bdn_outc_bwd (per-block partial classifier gradients)."""
         if self._outc_ws is None:
@@ -195,7 +200,7 @@ class BiDateEngine:
         # tools/experimental/ the code).
         self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
-        self._handoffs = []             # reusable device-local events, one per hand-off of a backward pass
+        self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
         self._prof_seen = 0
@@ -288,6 +293,13 @@ class BiDateEngine:
 
     def invalidate_weights(self):
         self._packed_valid = False
+
+    def release_split_buffers(self):
+        """Drop the bf16x3 operand-split buffers of every workspace nobody leases (see Workspace.release_split)."""
+        for pool in self._ws.values():
+            for ws in pool:
+                if not ws.leased:
+                    ws.release_split()
 
     def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st, reuse_eval_bn=False):
         hk, wk = ws.dims[L.level - 1]
@@ -483,10 +495,12 @@ class BiDateEngine:
         def handoff(src, dst):
             """Order what `dst` enqueues from now on behind what `src` has enqueued: a device-local event without the system-scope
             fence of a default event (streams.HandOff; 6.213 -> 6.187 ms per step in one process), one reusable event per hand-off."""
-            if n_hand[0] == len(self._handoffs):
+            pool = self._handoffs.setdefault(dev.index, [])      # events belong to the device they were created on
+            if n_hand[0] == len(pool):
                 from .streams import HandOff
-                self._handoffs.append(HandOff())
-            ho = self._handoffs[n_hand[0]]
+                with torch.cuda.device(dev):
+                    pool.append(HandOff())
+            ho = pool[n_hand[0]]
             n_hand[0] += 1
             ho.signal(src)
             ho.wait(dst)

@@ -116,6 +116,14 @@ class BiDateNet(nn.Module):
             self._engine.invalidate_weights()
         return out
 
+    def train(self, mode=True):
+        """nn.Module.train / eval; leaving training mode also drops the bf16x3 setting's per-layer operand-split buffers (about 1.5 GB
+        per trained workspace at B=16, 128x128; re-grown on demand by the next training forward)."""
+        out = super().train(mode)
+        if not mode and getattr(self, '_engine', None) is not None and self._engine.x3:
+            self._engine.release_split_buffers()
+        return out
+
     # the engine and its workspaces are derived state: keep them out of pickles / deepcopies
     def __getstate__(self):
         d = self.__dict__.copy()

@@ -43,8 +43,26 @@ def make_loaders(full_load, val_cities, patch_size, stride, batch_size, augmenta
     val_ds = OneraPreloader('', val_meta, full_load, patch_size, False)
     sampler = ShardSampler(len(train_ds), rank, world_size, seed=seed)
     kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=True)   # pinned batches: the copy stream DMAs them without staging
-    return (torch.utils.data.DataLoader(train_ds, sampler=sampler, drop_last=True, **kw),
+    # Augmentation draws (global `random`, utils/dataloaders.py:150-156) must differ between ranks.  With worker processes every worker
+    # re-seeds `random` from base_seed + worker_id, and base_seed comes from the loader's generator: torch.manual_seed(seed) makes that
+    # identical on every rank, so the loader gets a PER-RANK generator, and each worker additionally folds the rank into its seed.
+    gen = torch.Generator()
+    gen.manual_seed(seed * 7919 + rank)
+    return (torch.utils.data.DataLoader(train_ds, sampler=sampler, drop_last=True, generator=gen,
+                                        worker_init_fn=_RankWorkerSeed(seed, rank), **kw),
             torch.utils.data.DataLoader(val_ds, shuffle=False, **kw))
+
+
+class _RankWorkerSeed:
+    """worker_init_fn: Python's `random` of loader worker w on rank r is seeded from (seed, r, w, the worker's torch seed -- which the
+    loader advances every epoch)."""
+
+    def __init__(self, seed, rank):
+        self.seed, self.rank = int(seed), int(rank)
+
+    def __call__(self, worker_id):
+        import random
+        random.seed((self.seed * 7919 + self.rank) * 1000003 + worker_id * 65537 + torch.initial_seed() % 65521)
 
 
 def train_epoch(step, loader, dev, patch_size, feeder=None):

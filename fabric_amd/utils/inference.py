@@ -162,17 +162,19 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
         else torch.empty(h, w, dtype=torch.uint8, device=dev)
     seen = set()
     st = _lib.stream_ptr()
-    for i in range(lo, hi, batch_size):
-        j = min(hi, i + batch_size)
-        o = origins[i:j]
-        nb = o.shape[0]
+    try:
+        for i in range(lo, hi, batch_size):
+            j = min(hi, i + batch_size)
+            o = origins[i:j]
+            nb = o.shape[0]
+            if feed is not None:
+                feed.need_rows(int(o_np[i:j, 0].max()) + patch_size)       # the current stream waits for the last band these tiles read
+            logits, _ = eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen)
+            seen.add(nb)
+            call('bdn_argmax_stitch', ptr(logits), ptr(o), ptr(mask), nb, logits.shape[1], patch_size, h, w, st)
+    finally:
         if feed is not None:
-            feed.need_rows(int(o_np[i:j, 0].max()) + patch_size)       # the current stream waits for the last band these tiles read
-        logits, _ = eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen)
-        seen.add(nb)
-        call('bdn_argmax_stitch', ptr(logits), ptr(o), ptr(mask), nb, logits.shape[1], patch_size, h, w, st)
-    if feed is not None:
-        feed.close()
+            feed.close()          # also on an exception: the consumer stream joins every upload before the planes can be freed
     if shard is not None and merge and shard[1] > 1:
         import torch.distributed as dist
         dist.all_reduce(mask, op=dist.ReduceOp.MAX)
@@ -201,6 +203,10 @@ class _SceneFeeder:
             # by kernels that stream has queued)
             self.d1 = torch.empty(C, H, W, dtype=torch.float32, device=dev)
             self.d2 = torch.empty(C, H, W, dtype=torch.float32, device=dev)
+            alloc = torch.cuda.Event()
+            alloc.record(self.copy)
+        self.copy2.wait_event(alloc)          # d2 came from the copy stream's pool: whatever that stream still has queued on the block
+        self.d2.record_stream(self.copy2)     # (a feeder that just closed) precedes copy2's writes, and the block is not re-used under them
         self.events, self.waited, self.issued = [], -1, 0
         self.nbands = -(-H // band_rows)
         self.pinned = all(t.is_pinned() for t in self.src)
@@ -253,6 +259,9 @@ class _SceneFeeder:
             self.waited = k
 
     def close(self):
-        self.need_rows(self.H)
-        if self.pool is not None:
-            self.pool.shutdown(wait=True)
+        try:
+            self.need_rows(self.H)
+        finally:
+            if self.pool is not None:
+                self.pool.shutdown(wait=True)
+                self.pool = None

@@ -281,3 +281,32 @@ def test_bench_launches_its_own_ranks_or_refuses():
     env.pop('BENCH_ASSUME_DEVICES')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 2 and 'refusing' in r.stderr and not r.stdout.strip()
+
+
+class _DrawDataset(torch.utils.data.Dataset):
+    """Returns the augmentation draw itself: what utils/dataloaders.py:150-156 consumes from the global `random`."""
+
+    def __len__(self):
+        return 16
+
+    def __getitem__(self, i):
+        return torch.tensor([random.random(), random.random()], dtype=torch.float64)
+
+
+def test_augmentation_draws_differ_between_ranks_with_loader_workers():
+    """torch.manual_seed(seed) is the same on every rank, and loader workers seed `random` from the loader's base seed: without a
+    per-rank generator / worker_init_fn every rank would draw the same flips and rotations.  make_loaders' loader
+    arguments, on a dataset that returns the draws."""
+    from fabric_amd.train import _RankWorkerSeed
+
+    def draws(rank, epochs=2):
+        torch.manual_seed(7)                                   # what train.py does on every rank
+        gen = torch.Generator()
+        gen.manual_seed(7 * 7919 + rank)
+        dl = torch.utils.data.DataLoader(_DrawDataset(), batch_size=4, num_workers=2, generator=gen, worker_init_fn=_RankWorkerSeed(7, rank))
+        return [torch.cat([b for b in dl]) for _ in range(epochs)]
+
+    r0, r1, r0_again = draws(0), draws(1), draws(0)
+    assert not torch.equal(r0[0], r1[0]), 'two ranks drew the same augmentation sequence'
+    assert torch.equal(r0[0], r0_again[0]) and torch.equal(r0[1], r0_again[1]), 'a rank must be reproducible'
+    assert not torch.equal(r0[0], r0[1]), 'a new epoch must draw a new sequence'
