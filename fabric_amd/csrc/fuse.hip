@@ -361,16 +361,20 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dU, int ldU, T* __re
     }
 }
 
-// Tiled variant: a block owns 8x8 source pixels x 4 channel units (32 KB of LDS: small enough to share a CU with
-// the weight-gradient GEMM that runs beside the chain on the second stream).  The 20x20 destination pixels that can reach
-// them ([2y-2, 2y+3] per axis, see above) are staged ONCE in LDS (one coalesced pass over dU, 1.56x halo overhead
-// instead of the ~3x re-reads of the per-pixel gather), then every thread gathers two source pixels from LDS with
-// the same separable weights.
-template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const T* __restrict__ dU, int ldU, T* __restrict__ dsrc,
+// Tiled variant: a block owns 8x8 source pixels x UB channel units.  The 20x20 destination pixels that can reach them
+// ([2y-2, 2y+3] per axis, see above) are staged ONCE in LDS (one coalesced pass over dU, 1.56x halo overhead instead of the ~3x
+// re-reads of the per-pixel gather), then every thread gathers source pixels from LDS with the same separable weights.
+// UB = 8 (round 4; 64 channels = the whole 128-byte channel row of a pixel of the decoder's gradient slices, 56 KB of LDS) where C
+// allows it: with UB = 4 a block read 64-byte halves of 128-byte lines (level 1: 99 us for 168 MB).  UB = 4 (32 KB) otherwise.
+// Optionally (z_prev != NULL) the block also leaves the BatchNorm-backward partial sums of the layer whose relu(bn(z_prev)) was
+// upsampled -- sum g and sum g*z_prev over its 64 source pixels, g = (rounded) dsrc * [scale*z_prev + shift > 0] -- so that the
+// three decoder layers behind an upsampling need no reduction pass over dsrc and z either (every other producer of a dA had them).
+template <typename T, int UB>
+__global__ __launch_bounds__(UB == 8 ? 512 : 256) void upsample2x_bwd_tiled_kernel(const T* __restrict__ dU, int ldU, T* __restrict__ dsrc,
                                                                  int h, int w, int H, int W, int C, int tiles_x, int tiles_y,
-                                                                 float sy, float sx) {
-    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, UB = 4, PSTR = UB * 16 + 16;    // 80-byte pixel stride
+                                                                 float sy, float sx, const T* __restrict__ z_prev, const float* __restrict__ bn_prev,
+                                                                 float* __restrict__ bs_partial) {
+    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, PSTR = UB * 16 + 16, NT = 64 * UB;      // one thread per (source pixel, unit)
     __shared__ __attribute__((aligned(16))) unsigned char sm[R * R * PSTR];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -378,28 +382,34 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const T* __re
     const int ys0 = ty * TS, xs0 = tx * TS;
     const int top = (H - 2 * h) / 2, left = (W - 2 * w) / 2;
     // ---- stage the destination window (zero outside the upsampled image): all loads in flight before the first LDS store
-    constexpr int NL = (R * R * UB + 255) / 256;
+    constexpr int NL = (R * R * UB + NT - 1) / NT;
     uint4 stg[NL];
 #pragma unroll
     for (int j = 0; j < NL; j++) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         const int su = i % UB, pix = i / UB, rx = pix % R, ry = pix / R;
         const int dy = 2 * ys0 - 2 + ry, dx = 2 * xs0 - 2 + rx;
         stg[j] = make_uint4(0, 0, 0, 0);
         if (i < R * R * UB && dy >= 0 && dy < 2 * h && dx >= 0 && dx < 2 * w)
             stg[j] = *reinterpret_cast<const uint4*>(dU + ((size_t)(n * H + dy + top) * W + dx + left) * ldU + c0 + su * EPU);
     }
+    const int uu = tid % UB, sp = tid / UB;                      // 64 source pixels x UB units
+    const int ly = sp >> 3, lx = sp & 7;
+    const int y = ys0 + ly, x = xs0 + lx;
+    const bool live = y < h && x < w;
+    const bool bs = z_prev != nullptr;
+    uint4 zq = make_uint4(0, 0, 0, 0);
+    if (bs && live) zq = *reinterpret_cast<const uint4*>(z_prev + ((size_t)(n * h + y) * w + x) * C + c0 + uu * EPU);
 #pragma unroll
     for (int j = 0; j < NL; j++) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         if (i < R * R * UB) *reinterpret_cast<uint4*>(sm + (i / UB) * PSTR + (i % UB) * 16) = stg[j];
     }
     __syncthreads();
-    const int uu = tid % UB, sp = tid / UB;                      // 64 source pixels x 4 units
-    {
-        const int ly = sp >> 3, lx = sp & 7;
-        const int y = ys0 + ly, x = xs0 + lx;
-        if (y >= h || x >= w) return;
+    float s0[EPU], s1[EPU];
+#pragma unroll
+    for (int i = 0; i < EPU; i++) { s0[i] = 0.f; s1[i] = 0.f; }
+    if (live) {
         float wy[6], wx[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -426,26 +436,83 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const T* __re
                 for (int i = 0; i < EPU; i++) o[i] += wgt * f[i];
             }
         }
-        *reinterpret_cast<uint4*>(dsrc + ((size_t)(n * h + y) * w + x) * C + c0 + uu * EPU) = Unit<T>::pack(o);
+        const uint4 ou = Unit<T>::pack(o);
+        *reinterpret_cast<uint4*>(dsrc + ((size_t)(n * h + y) * w + x) * C + c0 + uu * EPU) = ou;
+        if (bs) {                                                  // on the STORED (rounded) gradient, like every other producer
+            float g[EPU], fz[EPU];
+            Unit<T>::unpack(ou, g);
+            Unit<T>::unpack(zq, fz);
+            const float* ps = bn_row(bn_prev, 0, 2, C) + c0 + uu * EPU;
+            const float* ph = bn_row(bn_prev, 0, 3, C) + c0 + uu * EPU;
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                const float gg = fmaf(fz[i], ps[i], ph[i]) > 0.f ? g[i] : 0.f;
+                s0[i] = gg; s1[i] = gg * fz[i];
+            }
+        }
+    }
+    if (bs) {
+        // 64 source pixels per channel unit: lanes uu, uu + UB, ... of a wave hold the same channels -- butterfly over those lane bits,
+        // then the waves meet in LDS (the staged window is dead) in a fixed order
+#pragma unroll
+        for (int i = 0; i < EPU; i++) {
+#pragma unroll
+            for (int m = UB; m < 64; m <<= 1) { s0[i] += __shfl_xor(s0[i], m); s1[i] += __shfl_xor(s1[i], m); }
+        }
+        constexpr int NW = NT / 64;
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sm);                 // [NW waves][UB][2 EPU]
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane < UB) {
+#pragma unroll
+            for (int i = 0; i < EPU; i++) { red[(wv * UB + lane) * 2 * EPU + i] = s0[i]; red[(wv * UB + lane) * 2 * EPU + EPU + i] = s1[i]; }
+        }
+        __syncthreads();
+        if (tid < UB * 2 * EPU) {                                  // one thread per (unit, moment, channel)
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; k++) t += red[k * UB * 2 * EPU + tid];
+            const int u = tid / (2 * EPU), r = tid % (2 * EPU), mom = r / EPU, ch = r % EPU;
+            bs_partial[((size_t)tile * 2 + mom) * C + c0 + u * EPU + ch] = t;
+        }
     }
 }
 
-extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
-                                  int B, int h, int w, int H, int W, int C, void* stream) {
+static bool ups_bwd_tiled_ok(int dtype, int h, int w, int C) {
+    const int epu = dtype == BDN_BF16 ? 8 : 4;
+    return h >= 8 && w >= 8 && C % (4 * epu) == 0 && (dtype == BDN_BF16 || dtype == BDN_F32);
+}
+
+extern "C" int bdn_upsample2x_bwd_rows(int dtype, int B, int h, int w, int C) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || !ups_bwd_tiled_ok(dtype, h, w, C)) return 0;
+    return B * ((h + 7) / 8) * ((w + 7) / 8);
+}
+
+static int upsample2x_bwd_impl(int dtype, const void* dU, int ldU, void* dsrc, const void* z_prev, const float* bn_prev, float* bs_partial,
+                               int B, int h, int w, int H, int W, int C, void* stream) {
     if (!dU || !dsrc) BDN_FAIL(BDN_E_ARG, "upsample2x_bwd: null pointer");
     if (H < 2 * h || W < 2 * w || C % 16 || C > 1024 || 1024 % C || ldU < C || ldU % 16) BDN_FAIL(BDN_E_SHAPE, "upsample2x_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int npix = B * h * w;
     const float sy = up_scale(h), sx = up_scale(w);
     const int epu = dtype == BDN_BF16 ? 8 : 4;
-    if (h >= 8 && w >= 8 && C % (4 * epu) == 0 && (dtype == BDN_BF16 || dtype == BDN_F32)) {
+    if (ups_bwd_tiled_ok(dtype, h, w, C)) {
         const int tx = (w + 7) / 8, ty = (h + 7) / 8;
-        const dim3 grid(tx * ty * B, C / (4 * epu));
-        if (dtype == BDN_BF16) hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel<bf16s>, grid, dim3(256), 0, st, (const bf16s*)dU, ldU, (bf16s*)dsrc, h, w, H, W, C, tx, ty, sy, sx);
-        else hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)dU, ldU, (float*)dsrc, h, w, H, W, C, tx, ty, sy, sx);
+#ifdef UPS_BWD_UB4
+        const bool wide = false;                                   // timing-only build: the round-3 block shape
+#else
+        const bool wide = C % (8 * epu) == 0;                      // whole 128-byte (bf16) channel rows per pixel
+#endif
+        const dim3 grid(tx * ty * B, C / ((wide ? 8 : 4) * epu));
+#define UPS_BWD_LAUNCH(T_, UB_) hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<T_, UB_>), grid, dim3(64 * UB_), 0, st, (const T_*)dU, ldU, (T_*)dsrc, h, w, H, W, C, \
+                                                   tx, ty, sy, sx, (const T_*)z_prev, bn_prev, bs_partial)
+        if (dtype == BDN_BF16) { if (wide) UPS_BWD_LAUNCH(bf16s, 8); else UPS_BWD_LAUNCH(bf16s, 4); }
+        else { if (wide) UPS_BWD_LAUNCH(float, 8); else UPS_BWD_LAUNCH(float, 4); }
+#undef UPS_BWD_LAUNCH
         BDN_CHECK_LAUNCH("upsample2x_bwd_tiled");
         return BDN_OK;
     }
+    if (z_prev) BDN_FAIL(BDN_E_SHAPE, "upsample2x_bwd_bs: shape outside the tiled kernel (bdn_upsample2x_bwd_rows returned 0)");
     if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS;
         hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)dU, ldU, (bf16s*)dsrc, npix, h, w, H, W, C, sy, sx); }
     else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS;
@@ -453,6 +520,17 @@ extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc
     else BDN_FAIL(BDN_E_ARG, "upsample2x_bwd: bad dtype");
     BDN_CHECK_LAUNCH("upsample2x_bwd");
     return BDN_OK;
+}
+
+extern "C" int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
+                                  int B, int h, int w, int H, int W, int C, void* stream) {
+    return upsample2x_bwd_impl(dtype, dU, ldU, dsrc, nullptr, nullptr, nullptr, B, h, w, H, W, C, stream);
+}
+
+extern "C" int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* dsrc, const void* z_prev, const float* bn_prev,
+                                     float* bs_partial, int B, int h, int w, int H, int W, int C, void* stream) {
+    if (!z_prev || !bn_prev || !bs_partial) BDN_FAIL(BDN_E_ARG, "upsample2x_bwd_bs: null pointer");
+    return upsample2x_bwd_impl(dtype, dU, ldU, dsrc, z_prev, bn_prev, bs_partial, B, h, w, H, W, C, stream);
 }
 
 // ============================================================ backward of product fusion + max-pool into encoder outputs

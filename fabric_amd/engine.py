@@ -25,6 +25,7 @@ ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+FUSE_UPS_BS = 1          # tools/ab_attr.py switch: upsample2x_bwd leaves the BatchNorm-backward partial sums (0: separate reduction pass)
 
 
 def _round_up(v, m):
@@ -119,6 +120,8 @@ class Workspace:
             n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg) * 2 * L.cout)
             if L.name == 'd4b':
                 n_stats = max(n_stats, lib.bdn_outc_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
+            if not L.enc and L.name[2] == 'b' and L.level > 1:      # upsample2x_bwd_bs leaves this layer's BatchNorm-backward partials here
+                n_stats = max(n_stats, lib.bdn_upsample2x_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             if L.enc:                                 # enc_skip_bwd leaves its BatchNorm-backward partials here too
                 n_stats = max(n_stats, 2 * lib.bdn_enc_skip_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             n_bnb = max(n_bnb, lib.bdn_bn_bwd_workspace_bytes(eng.dt, n, hk, wk, L.cout, ipg) // 4)
@@ -560,7 +563,7 @@ class BiDateEngine:
         rows_head = _lib.load().bdn_outc_bwd_rows(self.dt, B, H, W, L4b.cout)
         ready(['outc.conv.weight', 'outc.conv.bias'])
         # ---- decoder
-        dA_ptr, ldA = None, 0
+        dA_ptr, ldA, rows_up = None, 0, 0
         keep = []
         dcat = {}
         dF5 = None
@@ -578,7 +581,7 @@ class BiDateEngine:
                 call('bdn_outc_bn_bwd_apply', self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
                      ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dzb), B, hk, wk, Lb.cout, self.n_classes, st)
             else:
-                dzb = bn_bwd(Lb, dA_ptr, ldA, B, B)         # dA came from upsample2x_bwd: the one producer without fused sums
+                dzb = bn_bwd(Lb, dA_ptr, ldA, B, B, fused_rows=rows_up)     # dA came from upsample2x_bwd(_bs)
             wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
             dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
@@ -586,7 +589,14 @@ class BiDateEngine:
             dc = dgrad(La, dza, B, B)                       # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
             dcat[k] = dc
             dprev = e(B, hs, wsrc, cprev)
-            call('bdn_upsample2x_bwd', self.dt, dc.data_ptr() + ck * es, La.cin, ptr(dprev), B, hs, wsrc, hk, wk, cprev, st)
+            rows_up = _lib.load().bdn_upsample2x_bwd_rows(self.dt, B, hs, wsrc, cprev) if (j > 1 and FUSE_UPS_BS) else 0
+            if rows_up:
+                # the gradient lands on relu(bn(z)) of the previous decoder stage: its BatchNorm-backward partial sums come out of the same pass
+                Lp = by[f'd{j - 1}b']
+                call('bdn_upsample2x_bwd_bs', self.dt, dc.data_ptr() + ck * es, La.cin, ptr(dprev), ptr(ws.z[Lp.name]), ptr(ws.bn[Lp.name]),
+                     ptr(ws.stats), B, hs, wsrc, hk, wk, cprev, st)
+            else:
+                call('bdn_upsample2x_bwd', self.dt, dc.data_ptr() + ck * es, La.cin, ptr(dprev), B, hs, wsrc, hk, wk, cprev, st)
             keep += [dzb, dAa, dza, dprev]
             if j > 1:
                 dA_ptr, ldA = ptr(dprev), cprev

@@ -232,6 +232,14 @@ int bdn_upsample2x(int dtype, const void* src, int in_mode, const float* bn,
 /* Transpose of the above: dU: [B,H,W,ldU] channel slice -> dsrc: [B,h,w,C]. */
 int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
                        int B, int h, int w, int H, int W, int C, void* stream);
+/* The same with the BatchNorm-backward partial sums of the layer whose relu(bn(z_prev)) had been upsampled (up's input x1 is the
+ * previous double_conv's output, models/unet_parts.py:64-66 after :16-18) fused in: bs_partial f32
+ * [bdn_upsample2x_bwd_rows(dtype,B,h,w,C)][2][C] = per block sum g, sum g*z_prev with g = dsrc * [scale*z_prev + shift > 0]
+ * (z_prev [B,h,w,C], bn_prev [1][4][C]; one statistic group) -> bdn_bn_bwd_apply(raw_moment = 1).  rows() is 0 for shapes the
+ * tiled kernel does not take (maps below 8x8, C not a multiple of 32 (bf16) / 16 (f32)): use bdn_upsample2x_bwd + bdn_bn_bwd there. */
+int bdn_upsample2x_bwd_rows(int dtype, int B, int h, int w, int C);
+int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* dsrc, const void* z_prev, const float* bn_prev,
+                          float* bs_partial, int B, int h, int w, int H, int W, int C, void* stream);
 
 /* ---- backward of the date fusion and of MaxPool2d into the encoder outputs ----
  * dF: [B,H,W,ldF] slice; z: [2B,H,W,C], bn [2][4][C]; dP: NULL or [2B,H/2,W/2,C] gradient of the

@@ -301,6 +301,28 @@ def test_upsample2x_and_backward(prec, case, bnrelu):
     _lib.call('bdn_upsample2x_bwd', dt, dU_d.data_ptr() + extra * es, C + extra, dsrc.data_ptr(), B, h, w, H, W, C, st())
     torch.cuda.synchronize()
     assert_close('upsample bwd', from_nhwc(dsrc), a_req.grad.float(), 1e-5 if prec == 'fp32' else 8e-3)
+    # the same pass with the BatchNorm-backward partial sums of the upsampled layer fused in (where the tiled kernel takes the shape):
+    # identical dsrc, and sum g / sum g*z over the STORED gradient, g = dsrc * [scale*z + shift > 0]
+    rows = _lib.load().bdn_upsample2x_bwd_rows(dt, B, h, w, C)
+    if rows == 0:
+        with pytest.raises(RuntimeError, match='outside the tiled kernel'):
+            t = torch.zeros(16, device='cuda')
+            _lib.call('bdn_upsample2x_bwd_bs', dt, dU_d.data_ptr() + extra * es, C + extra, dsrc.data_ptr(), t.data_ptr(), t.data_ptr(),
+                      t.data_ptr(), B, h, w, H, W, C, st())
+        return
+    zp = rnd(prec, _rand((B, C, h, w), 48))
+    bnp = bn_table(1, C, 49)
+    dsrc2 = torch.empty_like(dsrc)
+    part = torch.full((rows, 2, C), float('nan'), device='cuda')
+    zp_d, bnp_d = to_nhwc(prec, zp), dev(bnp)
+    _lib.call('bdn_upsample2x_bwd_bs', dt, dU_d.data_ptr() + extra * es, C + extra, dsrc2.data_ptr(), zp_d.data_ptr(), bnp_d.data_ptr(),
+              part.data_ptr(), B, h, w, H, W, C, st())
+    torch.cuda.synchronize()
+    assert torch.equal(dsrc2, dsrc)
+    g = from_nhwc(dsrc2).double() * ((zp * bnp[0, 2][None, :, None, None] + bnp[0, 3][None, :, None, None]) > 0)
+    got = part.cpu().double().sum(0)
+    assert_close('upsample bwd: sum g', got[0], g.sum((0, 2, 3)), 2e-5 if prec == 'fp32' else 1e-4, 1e-4)
+    assert_close('upsample bwd: sum g z', got[1], (g * zp.double()).sum((0, 2, 3)), 2e-5 if prec == 'fp32' else 1e-4, 1e-4)
 
 
 @pytest.mark.parametrize('prec', PRECS)

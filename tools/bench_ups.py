@@ -15,3 +15,12 @@ for (B,h,w,C,ld) in [(64,64,64,64,128),(64,32,32,128,256),(64,16,16,256,512),(64
     t=e0.elapsed_time(e1)/10*1e3
     mb=(B*H*W*C*2+B*h*w*C*2)/1e6
     print(f'ups_bwd {h}x{w} C={C}: {t:.1f} us  {mb/t*1e-3*1e3/1e3:.2f} TB/s eff ({mb:.0f} MB)')
+    rows=_lib.load().bdn_upsample2x_bwd_rows(1,B,h,w,C)
+    if rows:
+        z=torch.randn(B,h,w,C,device='cuda').bfloat16(); bn=torch.rand(1,4,C,device='cuda')+0.5; part=torch.empty(rows,2,C,device='cuda')
+        f=lambda: _lib.call('bdn_upsample2x_bwd_bs', 1, dU.data_ptr()+ (ld-C)*2, ld, out.data_ptr(), z.data_ptr(), bn.data_ptr(), part.data_ptr(), B,h,w,H,W,C,st)
+        f(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        print(f'   with fused BatchNorm-backward sums: {e0.elapsed_time(e1)/10*1e3:.1f} us ({rows} rows)')
