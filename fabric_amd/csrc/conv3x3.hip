@@ -107,7 +107,12 @@ struct ConvCfg {
 template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
-__global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+// the multi-chunk 64-wide instantiation on 8 x 16 tiles needs 171 registers: at three blocks per CU (168) it spilled three of them;
+// two blocks per CU measure the same (d1a fwd 74.6 -> 73.8 us, step 6.16 ms either way) without scratch
+#ifndef CONV_N64_BLOCKS
+#define CONV_N64_BLOCKS 2
+#endif
+__global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8 && !D3) ? CONV_N64_BLOCKS : 3) : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;

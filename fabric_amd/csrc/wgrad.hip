@@ -63,9 +63,10 @@ __device__ __forceinline__ uint4 tr_pair(const unsigned char* p0, const unsigned
 // KSPLIT: for inputs with <= 32 channels the second half of the 64-wide ci tile is empty; the two waves
 // that would own it take every other 16-pixel k-step instead and write their own partial slice.
 // f32: nine 32x32 accumulators + 20 staging units of 16 bytes do not fit 256 registers (33-51 spilled in round 1), so the f32
-// instantiations are compiled for one block per CU
+// instantiations are compiled for one block per CU -- and so is KSPLIT (the 3-band configuration's first layer; 5 registers short of
+// two blocks per CU, and a spill's scratch traffic queues behind the prefetch loads)
 template <typename T, int TH, int TW, int TI, bool KSPLIT>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 || KSPLIT) ? 1 : 2) void wgrad_kernel(WgradArgs a) {
     using CF = WgCfg<T, TH, TW, TI>;
     using TL = typename CF::TL;
     constexpr int STR = CF::STR, EPU = ET<T>::EPU, UPP = CF::CKB / 16;
@@ -165,20 +166,28 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void wgrad_kernel(Wgra
             // of the 16-channel block ((lane>>4)&1) of this wave's 32 channels
             const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
             const int kpix = (lane & 15) >> 2;
-#pragma unroll 2
-            for (int ks = kpar; ks < TL::BM / 16; ks += KSPLIT ? 2 : 1) {
-                const int s0 = ks * 16 + half * 8 + kpix;            // k = 8*half + [0,4) ; +4 for the second read
-                const uint4 af = tr_pair(dzt + s0 * STR + wm * 64 + chan_b, dzt + (s0 + 4) * STR + wm * 64 + chan_b);
-                const unsigned char* pb0 = patch + TL::slot_to_pix(s0) * STR + wn * 64 + chan_b;
-                const unsigned char* pb1 = patch + TL::slot_to_pix(s0 + 4) * STR + wn * 64 + chan_b;
-#pragma unroll
-                for (int tap = 0; tap < 9; tap++) {
-                    const int tapoff = ((tap / 3) * TL::PW + (tap % 3)) * STR;
-                    const uint4 bfr = tr_pair(pb0 + tapoff, pb1 + tapoff);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
-                                                                       __builtin_bit_cast(bf16x8, bfr), acc[tap], 0, 0, 0);
-                }
+#define WG_KSTEP()                                                                                       \
+            {                                                                                           \
+                const int s0 = ks * 16 + half * 8 + kpix;            /* k = 8*half + [0,4) ; +4 for the second read */ \
+                const uint4 af = tr_pair(dzt + s0 * STR + wm * 64 + chan_b, dzt + (s0 + 4) * STR + wm * 64 + chan_b); \
+                const unsigned char* pb0 = patch + TL::slot_to_pix(s0) * STR + wn * 64 + chan_b;        \
+                const unsigned char* pb1 = patch + TL::slot_to_pix(s0 + 4) * STR + wn * 64 + chan_b;    \
+                _Pragma("unroll") for (int tap = 0; tap < 9; tap++) {                                    \
+                    const int tapoff = ((tap / 3) * TL::PW + (tap % 3)) * STR;                           \
+                    const uint4 bfr = tr_pair(pb0 + tapoff, pb1 + tapoff);                              \
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),  \
+                                                                       __builtin_bit_cast(bf16x8, bfr), acc[tap], 0, 0, 0); \
+                }                                                                                       \
             }
+            if constexpr (KSPLIT) {
+                // <= 32 input channels (the 3-band configuration): two k-steps in flight cost this instantiation 5 spilled registers
+#pragma unroll 1
+                for (int ks = kpar; ks < TL::BM / 16; ks += 2) WG_KSTEP()
+            } else {
+#pragma unroll 2
+                for (int ks = 0; ks < TL::BM / 16; ks++) WG_KSTEP()
+            }
+#undef WG_KSTEP
         } else {
 #pragma unroll 2
             for (int ks = kpar; ks < TL::BM / 2; ks += KSPLIT ? 2 : 1) {
