@@ -112,7 +112,7 @@ template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, b
 #ifndef CONV_N64_BLOCKS
 #define CONV_N64_BLOCKS 2
 #endif
-__global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8 && !D3) ? CONV_N64_BLOCKS : 3) : 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8) ? CONV_N64_BLOCKS : 3) : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
