@@ -29,7 +29,7 @@ void bdn_set_error(const char* fmt, ...);
 
 // bf16x3 helpers defined in x3.hip, used by the dtype dispatch of bdn_pack_weights / bdn_conv3x3_wgrad_ex
 int bdn_pack_weights_x3(const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int Cin_pad, hipStream_t st);
-int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, hipStream_t st);
+int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, int taps, hipStream_t st);
 
 // ---------------------------------------------------------------- element traits
 template <typename T> struct ET;

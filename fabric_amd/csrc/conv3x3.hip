@@ -667,10 +667,10 @@ extern "C" int bdn_conv3d_num_mtiles(int N, int D, int H, int W) {
     return conv3d_plan(N * D, H, W, 64).g.n_mtiles;
 }
 
-template <typename T, int CKB>
+template <typename T, int CKB, typename TO = T>
 static int dispatch_conv3d(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
-    if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, false, T, true>(a, p.g.n_mtiles, st);
-    return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2, false, T, true>(a, p.g.n_mtiles, st);
+    if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, false, TO, true>(a, p.g.n_mtiles, st);
+    return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2, false, TO, true>(a, p.g.n_mtiles, st);
 }
 
 // in: [N,D,H,W,C]; w: bdn_pack_weights image of the OIHW view [Cout][3 C][3][3] whose input channel kd*C + c is tap kd of channel c
@@ -684,9 +684,12 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     if (Cout <= 0 || Cout % 64 || C <= 0 || C % 16) BDN_FAIL(BDN_E_SHAPE, "conv3d: Cout=%d must be a multiple of 64, C=%d of 16", Cout, C);
     if (in_mode != BDN_IN_PLAIN && in_mode != BDN_IN_BNRELU) BDN_FAIL(BDN_E_ARG, "conv3d: bad in_mode %d", in_mode);
     if (in_mode == BDN_IN_BNRELU && !in_bn) BDN_FAIL(BDN_E_ARG, "conv3d: BNRELU input needs in_bn");
-    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3d: bad dtype %d (bf16 / f32)", dtype);
-    const size_t es = dtype == BDN_BF16 ? 2 : 4, slice = (size_t)H * W * C * es;
-    if ((size_t)N * D * slice >= ((size_t)1 << 32) || (size_t)N * D * H * W * Cout * es >= ((size_t)1 << 32))
+    if (dtype != BDN_BF16 && dtype != BDN_F32 && dtype != BDN_BF16X3) BDN_FAIL(BDN_E_ARG, "conv3d: bad dtype %d (bf16 / f32 / bf16x3)", dtype);
+    // bf16x3: `in` is the bf16 operand [N,D,H,W,C] with C = 3 x the logical width, channels [hi | lo | hi] of the float32 tensor (bdn_split_pack
+    // + a repeat of its hi half), `w` the plain bf16 image of the view whose channels are [w_hi | w_hi | w_lo] per depth tap; out is float32
+    if (dtype == BDN_BF16X3 && in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3d(bf16x3): plain operand (the split applies BatchNorm+ReLU)");
+    const size_t es = dtype == BDN_F32 ? 4 : 2, oes = dtype == BDN_BF16 ? 2 : 4, slice = (size_t)H * W * C * es;
+    if ((size_t)N * D * slice >= ((size_t)1 << 32) || (size_t)N * D * H * W * Cout * oes >= ((size_t)1 << 32))
         BDN_FAIL(BDN_E_SHAPE, "conv3d: a tensor reaches 4 GB (32-bit byte offsets inside the kernel); split the batch");
     ConvArgs a;
     a.in1 = in; a.in0 = static_cast<const unsigned char*>(in) - slice; a.in2 = static_cast<const unsigned char*>(in) + slice;
@@ -698,6 +701,7 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     const ConvPlan p = conv3d_plan(N * D, H, W, Cout);
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == BDN_BF16X3) return C % 64 == 0 ? dispatch_conv3d<bf16s, 128, float>(a, p, st) : dispatch_conv3d<bf16s, 32, float>(a, p, st);
     if (dtype == BDN_BF16) return C % 64 == 0 ? dispatch_conv3d<bf16s, 128>(a, p, st) : dispatch_conv3d<bf16s, 32>(a, p, st);
     return C % 32 == 0 ? dispatch_conv3d<float, 128>(a, p, st) : dispatch_conv3d<float, 64>(a, p, st);
 }

@@ -849,7 +849,7 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
         const int rc = bdn_conv3x3_wgrad_ex(BDN_BF16, dz, 2 * Cout, in0, 2 * C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group,
                                             partial, tile, 2 * C0, N, H, W, phases | WG_X3_SKIP, stream);
         if (rc) return rc;
-        if (phases & 2) return bdn_wgrad_x3_combine(tile, dw_oihw, Cout, C0, Cin_real, reinterpret_cast<hipStream_t>(stream));
+        if (phases & 2) return bdn_wgrad_x3_combine(tile, dw_oihw, Cout, C0, Cin_real, 9, reinterpret_cast<hipStream_t>(stream));
         return BDN_OK;
     }
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
@@ -945,7 +945,17 @@ extern "C" int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void*
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: bad N=%d D=%d H=%d W=%d", N, D, H, W);
     if (Cout <= 0 || Cout % 64 || C <= 0 || C % 16 || Cin_real <= 0 || Cin_real > C)
         BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: Cout=%d must be a multiple of 64, C=%d of 16, Cin_real=%d <= C", Cout, C, Cin_real);
-    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3d_wgrad: bad dtype %d (bf16 / f32)", dtype);
+    if (dtype == BDN_BF16X3) {
+        // dz [N,D,H,W,2 Cout] and in [N,D,H,W,2 C] are bdn_split_pack operands (hi | lo): the bf16 GEMM on the doubled operands gives
+        // T = [2 Cout][2 C][27] behind the split-K partials; dw = T[hi,hi] + T[hi,lo] + T[lo,hi]
+        if (Cout % 32 || C % 8) BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad(bf16x3): Cout=%d must be a multiple of 32, C=%d of 8", Cout, C);
+        const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N * D, H, W, 2 * Cout, 2 * C, 0, 1, BDN_IN_PLAIN, 0);
+        float* tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(partial) + gemm_bytes);
+        const int rc = bdn_conv3d_wgrad(BDN_BF16, dz, 2 * Cout, in, 2 * C, partial, tile, 2 * C, N, D, H, W, stream);
+        if (rc) return rc;
+        return bdn_wgrad_x3_combine(tile, dw_oidhw, Cout, C, Cin_real, 27, reinterpret_cast<hipStream_t>(stream));
+    }
+    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3d_wgrad: bad dtype %d (bf16 / f32 / bf16x3)", dtype);
     const int NS = N * D;
     const WgPlan p = wgrad_plan(dtype, NS, H, W, Cout, C, 0, 1 /* one slice per tile */, BDN_IN_PLAIN, 0);
     if (p.g.TI != 1) BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: internal plan error");

@@ -3,8 +3,8 @@
 # kernel-trace/stats off (gpurun refuses --pmc with trace domains).  Output: gpurun_out/pmc_traffic.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmct
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmct/f -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/pmct_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmct/w -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/pmct_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmct/f -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/pmct_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmct/w -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/pmct_w.log 2>&1
 python - <<'PY'
 import csv, glob, json, collections
 out = collections.defaultdict(lambda: {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
@@ -21,7 +21,7 @@ for k, v in out.items():
     res[k] = {'launches': n, 'fetch_bytes_per_launch_raw': v['FETCH_SIZE'] * 1024 / n,
               'fetch_bytes_per_launch_corrected': 2 * v['FETCH_SIZE'] * 1024 / n,
               'write_bytes_per_launch': v['WRITE_SIZE'] * 1024 / n}
-res['_meta'] = {'steps': 5, 'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras'}
+res['_meta'] = {'steps': 5, 'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --steps 3 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-extras'}
 json.dump(res, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
 for k in sorted([k for k in res if k != '_meta'], key=lambda k: -res[k]['fetch_bytes_per_launch_corrected'] * res[k]['launches'])[:8]:
     print(k[:60], {a: round(b / 1e6, 1) if a != 'launches' else b for a, b in res[k].items()})
