@@ -103,9 +103,13 @@ int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad,
  *   w      bdn_pack_weights image (wf) of the OIHW view [Cout][3 C][3][3] whose input channel kd*C + c holds w3d[co][c][kd][.][.]
  *          (data gradient: the same entry point on dz with the view [C][3 Cout][3][3], channel s*Cout + co = w3d[co][c][2-s][2-kh][2-kw])
  *   in_mode / in_bn / stats_partial / bias as in bdn_conv3x3; imgs_per_group counts samples;
- *   stats_partial rows: bdn_conv3d_num_mtiles(N, D, H, W).  dtype: BDN_BF16 or BDN_F32.
+ *   stats_partial rows: bdn_conv3d_num_mtiles(N, D, H, W).  dtype: BDN_BF16, BDN_F32, or BDN_BF16X3 (round 4) -- then `in` is the bf16
+ *   operand [N,D,H,W,C] whose C = 3 x the logical width holds [hi | lo | hi] of the float32 tensor (bdn_split_pack's [hi | lo] plus its hi
+ *   half again), `w` the plain BDN_BF16 image of the view with channels [w_hi | w_hi | w_lo] per depth tap, in_mode PLAIN, out float32.
  * bdn_conv3d_wgrad: dw [Cout][Cin_real][3][3][3] f32 from dz [N,D,H,W,Cout] and the PLAIN input [N,D,H,W,C];
- *   partial: bdn_wgrad_workspace_bytes_ex(dtype, N*D, H, W, Cout, C, 0, 1, BDN_IN_PLAIN, 0) bytes. */
+ *   partial: bdn_wgrad_workspace_bytes_ex(dtype, N*D, H, W, Cout, C, 0, 1, BDN_IN_PLAIN, 0) bytes.
+ *   BDN_BF16X3: dz [N,D,H,W,2 Cout] and in [N,D,H,W,2 C] are bdn_split_pack operands; partial: the BDN_BF16 size for (2 Cout, 2 C) plus
+ *   4*Cout*C*27 floats (the doubled-operand tile the three quadrants are summed from). */
 int bdn_conv3d_num_mtiles(int N, int D, int H, int W);
 int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const float* in_bn, int imgs_per_group,
                const void* w, const float* bias, void* out, float* stats_partial,

@@ -83,14 +83,14 @@ def _torch_block(cin, cout, seed):
 
 
 @pytest.mark.parametrize('prec,shape', [('fp32', (2, 5, 128, 128, 13, 64)), ('bf16', (2, 5, 128, 128, 13, 64)), ('fp32', (1, 3, 21, 40, 64, 128)),
-                                        ('bf16', (2, 2, 16, 48, 64, 64))])
+                                        ('bf16', (2, 2, 16, 48, 64, 64)), ('bf16x3', (2, 5, 128, 128, 13, 64)), ('bf16x3', (1, 3, 21, 40, 64, 128))])
 def test_double_conv3d_block_matches_torch_nn(prec, shape):
     """(Conv3d + BatchNorm3d + ReLU) x 2, training mode, forward AND backward, against the same stack of stock torch.nn modules on
     the CPU -- at the multi-date benchmark shape of BASELINE configs[3] (5 dates x 13 bands x 128 x 128, two samples) and at ragged
     sizes.  Parity unpinned against the reference (it has no source for a 3-D model): torch.nn is the only oracle."""
     from fabric_amd.conv3d import DoubleConv3d
     N, D, H, W, Cin, Cout = shape
-    td = torch.float32 if prec == 'fp32' else torch.bfloat16
+    td = torch.bfloat16 if prec == 'bf16' else torch.float32          # bf16x3: float32 tensors, split bf16 GEMM operands
     ref = _torch_block(Cin, Cout, 5)
     x = _rand((N, Cin, D, H, W), 11)
     if prec == 'bf16':
@@ -107,16 +107,16 @@ def test_double_conv3d_block_matches_torch_nn(prec, shape):
     dx, grads = blk.backward(to_ndhwc(g.cuda(), Cout, td))
     torch.cuda.synchronize()
     got = out.float().cpu().permute(0, 4, 1, 2, 3)
-    tol = 2e-4 if prec == 'fp32' else 4e-2
+    tol = 4e-2 if prec == 'bf16' else 2e-4                       # bf16x3 is held to the float32 bound
     assert torch.isfinite(got).all()
     assert (got - y.detach()).abs().max() <= tol * y.detach().abs().max(), (got - y.detach()).abs().max()
     sd = ref.state_dict()
     for k in ('1', '4'):
         for buf in ('running_mean', 'running_var'):
             a, b = blk.P[f'conv.{k}.{buf}'].cpu(), sd[f'{k}.{buf}']
-            assert (a - b).abs().max() <= (1e-4 if prec == 'fp32' else 2e-2) * max(1.0, b.abs().max().item()), (k, buf)
+            assert (a - b).abs().max() <= (2e-2 if prec == 'bf16' else 1e-4) * max(1.0, b.abs().max().item()), (k, buf)
         assert int(blk.P[f'conv.{k}.num_batches_tracked']) == 1
-    gtol = 2e-3 if prec == 'fp32' else 0.25                      # relative L2 per tensor (bf16: the 2-D path's bound is 0.8)
+    gtol = {'fp32': 2e-3, 'bf16x3': 6e-3, 'bf16': 0.25}[prec]    # relative L2 per tensor (bf16: the 2-D path's bound is 0.8; bf16x3: 6e-2 there)
     for k, p in ref.named_parameters():
         want, have = p.grad, grads[f'conv.{k}'].cpu()
         if k in ('0.bias', '3.bias'):
