@@ -70,6 +70,7 @@ SIGNATURES = {
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_conv3x3_dgrad_bb': (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),
     'bdn_bn_bwd_finalize': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_bwd_apply': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -131,9 +132,14 @@ def _profiled(lib, name, args):
     return rc
 
 
+SKIP = None           # timing diagnostics only (tools/ab_skip.py): callable(name, args) -> True drops the launch (results are then wrong)
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; raise RuntimeError with the library's message on failure."""
     lib = load()
+    if SKIP is not None and SKIP(name, args):
+        return
     if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is _vp and not name.startswith(('bdn_stream', 'bdn_event')):
         rc = _profiled(lib, name, args)
     else:

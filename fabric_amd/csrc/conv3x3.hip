@@ -40,6 +40,11 @@ struct ConvArgs {
     // is bs_bn; the epilogue then also emits that layer's BatchNorm-backward partial sums (stats_partial, same
     // [n_mtiles][2][Cout] layout):  sum_p g  and  sum_p g*z  with  g = dA * [scale*z + shift > 0]
     const void* bs_z; const float* bs_bn;
+    // data-gradient launches with the BatchNorm+ReLU backward of THIS layer applied while the input is staged (template flag BB; round 4):
+    // in0 = dA (gradient wrt relu(bn(z))), bb_z = the layer's raw output z [N,H,W,C0], bb_bn its table, bb_sums [G][2][C0] from
+    // bdn_bn_bwd_finalize; the staged operand is dz = scale * (g - s0/M - xhat * s1/M), g = dA * [scale z + shift > 0] -- bdn_bn_bwd_apply's
+    // expression, value for value -- and the blocks of column tile 0 also store their tile's dz to bb_dz (for the weight-gradient GEMM)
+    const void* bb_z; const float* bb_bn; const float* bb_sums; void* bb_dz; float bb_invM;
 };
 
 template <typename T> struct Mma;
@@ -104,7 +109,7 @@ struct ConvCfg {
 // ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 // the multi-chunk 64-wide instantiation on 8 x 16 tiles needs 171 registers: at three blocks per CU (168) it spilled three of them;
@@ -112,7 +117,7 @@ template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, b
 #ifndef CONV_N64_BLOCKS
 #define CONV_N64_BLOCKS 2
 #endif
-__global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8) ? CONV_N64_BLOCKS : 3) : 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8) ? CONV_N64_BLOCKS : 3) : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
     // shifted by a slice (pixel 0 of the lower one lies in front of the tensor), so the tile's own origin pixel
     const int p_fall = D3 ? (n0 * a.H + y0) * a.W + x0 : 0;
     constexpr bool BRANCHFREE = !ONE;
+    static_assert(!BB || (sizeof(T) == 2 && sizeof(TO) == 2 && !D3 && TI == 1), "BatchNorm backward on load: bf16 2-D launches, one image per tile");
     uint4 preg[NPU];
+    uint4 pregz[BB ? NPU : 1];                           // BB: the z units of the same pixels
 #define LOAD_PATCH(c0_)                                                                                  \
     {                                                                                                   \
         const T* src_; int cs_, Cs_;                                                                    \
@@ -178,6 +185,12 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
         const unsigned cb_ = (unsigned)Cs_ * CF::ES;                                                    \
         _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
             preg[i] = *reinterpret_cast<const uint4*>(sb_ + ((unsigned)(p_pix[i] >= 0 ? p_pix[i] : p_fall) * cb_ + p_subb)); \
+        if constexpr (BB) {                                                                             \
+            const unsigned char* zb_ = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(a.bb_z) + (c0_)); \
+            const unsigned zc_ = (unsigned)a.C0 * CF::ES;                                               \
+            _Pragma("unroll") for (int i = 0; i < NPU; i++)                                              \
+                pregz[i] = *reinterpret_cast<const uint4*>(zb_ + ((unsigned)(p_pix[i] >= 0 ? p_pix[i] : 0) * zc_ + p_subb)); \
+        }                                                                                               \
     }
 #define STORE_PATCH(c0_, buf_)                                                                           \
     {                                                                                                   \
@@ -191,6 +204,33 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
             const float* ps_ = bn_row(a.in_bn, grp, 2, a.C0) + bc_ + p_sub;                             \
             const float* ph_ = bn_row(a.in_bn, grp, 3, a.C0) + bc_ + p_sub;                             \
             _Pragma("unroll") for (int e = 0; e < EPU; e++) { sc_[e] = ps_[e]; sh_[e] = ph_[e]; }        \
+        }                                                                                               \
+        float bk_[BB ? 6 : 1][EPU];                        /* BB: mean, invstd, scale, shift, s0/M, s1/M of this thread's channels */ \
+        if constexpr (BB) {                                                                             \
+            _Pragma("unroll") for (int k = 0; k < 4; k++) {                                              \
+                const float* r_ = bn_row(a.bb_bn, grp, k, a.C0) + bc_ + p_sub;                          \
+                _Pragma("unroll") for (int e = 0; e < EPU; e++) bk_[k][e] = r_[e];                       \
+            }                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < 2; k++) {                                              \
+                const float* r_ = a.bb_sums + ((size_t)grp * 2 + k) * a.C0 + bc_ + p_sub;               \
+                _Pragma("unroll") for (int e = 0; e < EPU; e++) bk_[4 + k][e] = r_[e] * a.bb_invM;        \
+            }                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                            \
+                float fz_[EPU], fg_[EPU], o_[EPU];                                                      \
+                Unit<T>::unpack(pregz[i], fz_);                                                         \
+                Unit<T>::unpack(preg[i], fg_);                                                          \
+                _Pragma("unroll") for (int e = 0; e < EPU; e++) {                                        \
+                    const float gm_ = fmaf(fz_[e], bk_[2][e], bk_[3][e]) > 0.f ? fg_[e] : 0.f;           \
+                    const float xh_ = (fz_[e] - bk_[0][e]) * bk_[1][e];                                  \
+                    o_[e] = bk_[2][e] * (gm_ - bk_[4][e] - xh_ * bk_[5][e]);                             \
+                }                                                                                       \
+                preg[i] = Unit<T>::pack(o_);                                                            \
+                if (a.bb_dz != nullptr && ntile == 0 && p_pix[i] >= 0) {      /* the tile's own pixels: the weight-gradient GEMM reads them */ \
+                    const int u_ = tid + i * 256, pix_ = u_ / UPP, xx_ = pix_ % TL::PW, yy_ = (pix_ / TL::PW) % TL::PH;   \
+                    if (xx_ >= 1 && xx_ <= TW && yy_ >= 1 && yy_ <= TH)                                  \
+                        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.bb_dz) + ((unsigned)p_pix[i] * ((unsigned)a.C0 * CF::ES) + (unsigned)(bc_) * CF::ES + p_subb)) = preg[i]; \
+                }                                                                                       \
+            }                                                                                           \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
             const int u_ = tid + i * 256;                  /* LDS offset recomputed: cheaper than 11 live registers */ \
@@ -483,17 +523,17 @@ __global__ __launch_bounds__(256, (sizeof(TO) == sizeof(T) && ((ONE && BN == 64)
 static thread_local bool g_conv_query = false;
 static thread_local char g_conv_variant[160];
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     if (g_conv_query) {
         // the full template spelling, so that a profiler can match rocprofv3's kernel names exactly ("bf16" = unsigned short)
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s>",
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s%s>",
                  sizeof(T) == 2 ? "bf16" : "float", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false",
-                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false");
+                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? ",true" : "");
         return BDN_OK;
     }
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3>;
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB>;
     BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
@@ -550,6 +590,16 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     return launch_conv<T, CKB, 8, 8, 2, 64, 2, 2>(a, g.n_mtiles, st);
 }
 
+// BatchNorm backward on load (bdn_conv3x3_dgrad_bb): the single-chunk shapes only (dz of a 64-channel layer) -- there the staging runs once,
+// in the prologue; inside the main loop of the multi-chunk kernels the second operand and the six per-channel constants spill.
+static int dispatch_conv_bb(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+    const TileGeom& g = p.g;
+    if (g.TI != 1) BDN_FAIL(BDN_E_SHAPE, "conv3x3_dgrad_bb: maps of 8x8 and below are not supported");
+    if (g.TH == 16) return launch_conv<bf16s, 128, 16, 16, 1, 64, 2, 2, true, bf16s, false, true>(a, g.n_mtiles, st);
+    if (p.BN == 128) return launch_conv<bf16s, 128, 8, 16, 1, 128, 1, 4, true, bf16s, false, true>(a, g.n_mtiles, st);
+    return launch_conv<bf16s, 128, 8, 16, 1, 64, 2, 2, false, bf16s, false, true>(a, g.n_mtiles, st);
+}
+
 // bf16x3 setting: same tile geometry as the plan above (the caller sizes the statistics buffer from it), 64-wide column tiles,
 // float32 outputs; the reduction runs over 3*Cin channels (hi|lo of the split operand, then its hi part again).
 template <int CKB>
@@ -570,7 +620,8 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
                         int in_mode, const float* in_bn, int imgs_per_group,
                         const void* w, const float* bias, void* out, float* stats_partial,
                         const void* bs_z, const float* bs_bn,
-                        int N, int H, int W, int Cout, void* stream) {
+                        int N, int H, int W, int Cout, void* stream,
+                        const void* bb_z = nullptr, const float* bb_bn = nullptr, const float* bb_sums = nullptr, void* bb_dz = nullptr) {
     if (!in0 || !w || !out) BDN_FAIL(BDN_E_ARG, "conv3x3: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
         BDN_FAIL(BDN_E_SHAPE, "conv3x3: bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
@@ -598,10 +649,16 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
     a.bs_z = bs_z; a.bs_bn = bs_bn; a.in2 = nullptr; a.Dz = 0;
+    a.bb_z = bb_z; a.bb_bn = bb_bn; a.bb_sums = bb_sums; a.bb_dz = bb_dz; a.bb_invM = 1.f / (float)((size_t)imgs_per_group * H * W);
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (bb_z) {
+        if (dtype != BDN_BF16 || C0 != 64 || in1 || in_mode != BDN_IN_PLAIN)
+            BDN_FAIL(BDN_E_SHAPE, "conv3x3_dgrad_bb: bf16, one plain source of C0 = 64 channels (got %d)", C0);
+        return dispatch_conv_bb(a, g, st);
+    }
     if (dtype == BDN_BF16) {
         // channel chunk: 64 channels (128 B) when both sources allow it, else 16 channels (32 B)
         if (C0 % 64 == 0 && C1 % 64 == 0) return dispatch_conv<bf16s, 128>(a, g, st);
@@ -642,6 +699,20 @@ extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const voi
     if (!z_prev || !bn_prev || !bs_partial) BDN_FAIL(BDN_E_ARG, "conv3x3_dgrad_bs: null pointer");
     return conv3x3_impl(dtype, dz, C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group, w_dgrad, nullptr, dA, bs_partial,
                         z_prev, bn_prev, N, H, W, Cout, stream);
+}
+
+// Data gradient of layer L with L's BatchNorm+ReLU backward applied while dz is staged (bdn_bn_bwd_apply never runs, dz is written once
+// as a by-product for the weight-gradient GEMM): dA [N,H,W,C0] (ldA == C0), z / bn / sums of layer L (sums from bdn_bn_bwd_finalize).
+// z_prev / bn_prev / bs_partial: as bdn_conv3x3_dgrad_bs (all three NULL: no fused statistics of the producing layer).
+extern "C" int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const void* z, const float* bn, const float* sums, int imgs_per_group,
+                                    const void* w_dgrad, void* dA_prev, const void* z_prev, const float* bn_prev, float* bs_partial,
+                                    void* dz_out, int N, int H, int W, int Cout, void* stream) {
+    if (!z || !bn || !sums) BDN_FAIL(BDN_E_ARG, "conv3x3_dgrad_bb: null pointer");
+    if ((z_prev != nullptr) != (bn_prev != nullptr) || (z_prev != nullptr) != (bs_partial != nullptr))
+        BDN_FAIL(BDN_E_ARG, "conv3x3_dgrad_bb: z_prev, bn_prev and bs_partial come together");
+    if (H <= 8 && W <= 8) BDN_FAIL(BDN_E_SHAPE, "conv3x3_dgrad_bb: maps of 8x8 and below are not supported");
+    return conv3x3_impl(dtype, dA, C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group, w_dgrad, nullptr, dA_prev, bs_partial,
+                        z_prev, bn_prev, N, H, W, Cout, stream, z, bn, sums, dz_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -201,6 +201,9 @@ class BiDateEngine:
         # unfused BatchNorm-backward paths, relu(bn(z)) materialised for the weight gradient, the two-pass encoder skip backward,
         # release schedules of the weight-gradient GEMMs -- is gone from the product (DESIGN.md section 4 keeps the findings,
         # tools/experimental/ the code).
+        # layers (64 output channels) whose BatchNorm backward is applied inside their data-gradient conv (bdn_conv3x3_dgrad_bb) instead of by the
+        # bn_bwd_apply pass.  In-process A/B (tools/ab_fold.py): e1b -0.6 % step time, d4a +0.4 %, d3a+d3b +0.5 % -- only e1b is folded
+        self.fold_bn_bwd = ('e1b',)
         self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
@@ -451,6 +454,24 @@ class BiDateEngine:
                      ptr(sc['bnb']), ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(dz), st)
             return dz
 
+        def fold_dgrad(L, dA, n, ipg, fused_rows, prev=None):
+            """BatchNorm+ReLU backward of layer L applied while its data-gradient conv stages dz (no bn_bwd_apply pass): the partial sums in
+            ws.stats are finalized (sums, dgamma, dbeta), then ONE kernel forms dz on load, convolves it and stores it for the weight
+            gradient.  Returns (dz, dA_prev[, rows])."""
+            hk, wk = ws.dims[L.level - 1]
+            G = n // ipg
+            call('bdn_bn_bwd_finalize', ptr(ws.bn[L.name]), G, L.cout, ptr(ws.stats), fused_rows, 1, ptr(sc['sums']),
+                 ptr(grads[f'{L.bn}.weight']), ptr(grads[f'{L.bn}.bias']), ptr(ws.bnws), st)
+            _, wd = self._weights(L, P, True)
+            dz, out = e(n, hk, wk, L.cout), e(n, hk, wk, L.cin)
+            has = prev is not None
+            call('bdn_conv3x3_dgrad_bb', self.mdt, dA, L.cout, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ptr(sc['sums']), ipg, ptr(wd), ptr(out),
+                 ptr(ws.z[prev.name]) if has else None, ptr(ws.bn[prev.name]) if has else None, ptr(ws.stats) if has else None,
+                 ptr(dz), n, hk, wk, L.cin, st)
+            if has:
+                return dz, out, _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // G
+            return dz, out
+
         def wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, stp):
             """The weight-gradient GEMM and its reduction; with profiling on, the GEMM alone sits between two events
             recorded on the stream it is launched on."""
@@ -564,6 +585,7 @@ class BiDateEngine:
         ready(['outc.conv.weight', 'outc.conv.bias'])
         # ---- decoder
         dA_ptr, ldA, rows_up = None, 0, 0
+        fold = set(self.fold_bn_bwd) if (self.mdt == BDN_BF16) else set()
         keep = []
         dcat = {}
         dF5 = None
@@ -574,19 +596,28 @@ class BiDateEngine:
             La, Lb = by[f'd{j}a'], by[f'd{j}b']
             ck = ENC_CH[k - 1]
             cprev = La.cin - ck
+            folded_b = False
             if j == 4:
                 dzb = e(B, hk, wk, Lb.cout)
                 call('bdn_bn_bwd_finalize', ptr(ws.bn[Lb.name]), 1, Lb.cout, ptr(ws.stats), rows_head, 1, ptr(sc['sums']),
                      ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
                 call('bdn_outc_bn_bwd_apply', self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
                      ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dzb), B, hk, wk, Lb.cout, self.n_classes, st)
+            elif Lb.name in fold and rows_up and ldA == Lb.cout == 64:
+                dzb, dAa, rows = fold_dgrad(Lb, dA_ptr, B, B, rows_up, prev=La)
+                folded_b = True
             else:
                 dzb = bn_bwd(Lb, dA_ptr, ldA, B, B, fused_rows=rows_up)     # dA came from upsample2x_bwd(_bs)
             wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
-            dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
-            dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
-            wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
-            dc = dgrad(La, dza, B, B)                       # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
+            if not folded_b:
+                dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
+            if La.name in fold and La.cout == 64:
+                dza, dc = fold_dgrad(La, ptr(dAa), B, B, rows)
+                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
+            else:
+                dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
+                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
+                dc = dgrad(La, dza, B, B)                   # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
             dcat[k] = dc
             dprev = e(B, hs, wsrc, cprev)
             rows_up = _lib.load().bdn_upsample2x_bwd_rows(self.dt, B, hs, wsrc, cprev) if (j > 1 and FUSE_UPS_BS) else 0
@@ -616,9 +647,13 @@ class BiDateEngine:
             dAb = e(2 * B, hk, wk, ck)
             call('bdn_enc_skip_bwd', self.dt, dF_ptr, ldF, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]),
                  ptr(dP), ptr(dAb), ptr(ws.stats), B, hk, wk, ck, st)
-            dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
-            wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
-            dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
+            if Lb.name in fold and min(hk, wk) > 8 and Lb.cout == 64:
+                dzb, dAa, rows = fold_dgrad(Lb, ptr(dAb), 2 * B, B, rows_b, prev=La)
+                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
+            else:
+                dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
+                wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
+                dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
             if k == 1 and _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.mdt, 2 * B, hk, wk, La.cout, La.cin, B):
                 # the first conv has no data gradient: its dz has one reader, so the BatchNorm backward is applied inside
                 # that weight-gradient GEMM's staging and the largest tensor of the step is never written (on the main
@@ -647,8 +682,14 @@ class BiDateEngine:
                 keep += [dAb, dzb, dAa, dP]
                 dP = None
                 continue
-            dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
             src = ws.x0 if k == 1 else ws.pool[k]
+            if La.name in fold and k > 1 and min(hk, wk) > 8 and La.cout == 64:
+                dza, dP_new = fold_dgrad(La, ptr(dAa), 2 * B, B, rows)
+                wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
+                keep += [dAb, dzb, dAa, dza, dP]
+                dP = dP_new
+                continue
+            dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
             wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
             keep += [dAb, dzb, dAa, dza, dP]
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None

@@ -95,6 +95,17 @@ int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad,
                          const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
                          int N, int H, int W, int Cout, void* stream);
 
+/* Data gradient of layer L's convolution with L's BatchNorm+ReLU backward (autograd of models/unet_parts.py:14-15,17-18) applied while the
+ * operand is staged: dA [N,H,W,C0] = gradient wrt relu(bn(z)), z [N,H,W,C0], bn [G][4][C0], sums [G][2][C0] from bdn_bn_bwd_finalize;
+ * the kernel forms dz = scale*(g - s0/M - xhat*s1/M), g = dA*[scale z + shift > 0] (bdn_bn_bwd_apply's expression, value for value),
+ * convolves it with w_dgrad into dA_prev [N,H,W,Cout] and stores dz [N,H,W,C0] to dz_out (NULL: not stored) for the weight-gradient
+ * GEMM -- bdn_bn_bwd_apply's pass over dA, z and dz does not run.  z_prev / bn_prev / bs_partial: as bdn_conv3x3_dgrad_bs, or all NULL.
+ * bf16, C0 = 64 (a single channel chunk: the staging then runs once, in the kernel's prologue), maps larger than 8x8.  Measured in the
+ * training step (tools/ab_fold.py): pays for the last full-resolution layer only (inc's second conv), which is where the engine uses it. */
+int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const void* z, const float* bn, const float* sums, int imgs_per_group,
+                         const void* w_dgrad, void* dA_prev, const void* z_prev, const float* bn_prev, float* bs_partial,
+                         void* dz_out, int N, int H, int W, int Cout, void* stream);
+
 /* ---- 3x3x3 convolution, stride 1, zero padding 1 (BASELINE configs[3]: the multi-date 3-D U-Net stack) ----
  * The reference tree holds NO source for that model (UNetLSTM/ is an empty sub-module, README.md:5): parity is UNPINNED, the
  * oracle is torch.nn.functional.conv3d.  Implicit GEMM with K = 27 Cin on the 2-D kernels: tensors are [N,D,H,W,C] (the D

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from fabric_amd import _lib
-from fabric_amd._lib import IN_BNRELU, IN_PLAIN
+from fabric_amd._lib import BDN_BF16, IN_BNRELU, IN_PLAIN
 from oracle import bidate_oracle as O
 from tests.gpu_util import (DT, assert_close, bn_table, bnrelu_ref, dev, frag_to_dense, from_nhwc, pack_w, rnd, st,
                             to_nhwc)
@@ -118,6 +118,58 @@ def test_conv3x3_dgrad(prec, case):
               out.data_ptr(), None, N, H, W, Cin, st())
     torch.cuda.synchronize()
     assert_close('dgrad', from_nhwc(out), ref, TOL[prec])
+
+
+@pytest.mark.parametrize('case', [(2, 40, 24, 64, 64, 1, True), (4, 32, 32, 64, 128, 2, False), (2, 24, 20, 64, 64, 2, False),
+                                  (16, 64, 64, 64, 256, 8, True), (3, 17, 45, 64, 128, 3, True)])
+def test_conv3x3_dgrad_with_bn_backward_on_load(case):
+    """bdn_conv3x3_dgrad_bb = bdn_bn_bwd_apply + bdn_conv3x3(_dgrad_bs) without the pass in between: dz (the by-product) and the data
+    gradient must equal the two-kernel path BIT FOR BIT (same expression, same operand values, same MFMA order), with and without the
+    fused BatchNorm-backward statistics of the producing layer; the three single-chunk instantiations, ragged tiles."""
+    N, H, W, C0, Cout, ipg, with_bs = case
+    lib = _lib.load()
+    G = N // ipg
+    dA = rnd('bf16', _rand((N, C0, H, W), 61))
+    z = rnd('bf16', _rand((N, C0, H, W), 62))
+    bn = bn_table(G, C0, 63)
+    w = rnd('bf16', _rand((C0, Cout, 3, 3), 64, 0.05))          # layer L: Cout -> C0 channels; its data gradient maps C0 -> Cout
+    _, wd = pack_w('bf16', w, Cout)
+    dA_d, z_d, bn_d = to_nhwc('bf16', dA), to_nhwc('bf16', z), dev(bn)
+    # reference path: reduce + finalize + apply, then the plain data-gradient convolution
+    ws = torch.empty(lib.bdn_bn_bwd_workspace_bytes(BDN_BF16, N, H, W, C0, ipg) // 4, device='cuda')
+    sums = torch.empty(G, 2, C0, device='cuda')
+    dg, db = torch.empty(C0, device='cuda'), torch.empty(C0, device='cuda')
+    dz_ref = torch.empty(N, H, W, C0, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_bn_bwd', BDN_BF16, dA_d.data_ptr(), C0, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, C0,
+              ws.data_ptr(), sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz_ref.data_ptr(), st())
+    out_ref = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device='cuda')
+    nt = lib.bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
+    zp = to_nhwc('bf16', rnd('bf16', _rand((N, Cout, H, W), 65)))
+    bnp = dev(bn_table(G, Cout, 66))
+    part_ref = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    part = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    if with_bs:
+        _lib.call('bdn_conv3x3_dgrad_bs', BDN_BF16, dz_ref.data_ptr(), C0, wd.data_ptr(), out_ref.data_ptr(), zp.data_ptr(), bnp.data_ptr(), ipg,
+                  part_ref.data_ptr(), N, H, W, Cout, st())
+    else:
+        _lib.call('bdn_conv3x3', BDN_BF16, dz_ref.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg, wd.data_ptr(), None, out_ref.data_ptr(), None,
+                  N, H, W, Cout, st())
+    out = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device='cuda')
+    dz = torch.full((N, H, W, C0), float('nan'), dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_conv3x3_dgrad_bb', BDN_BF16, dA_d.data_ptr(), C0, z_d.data_ptr(), bn_d.data_ptr(), sums.data_ptr(), ipg, wd.data_ptr(),
+              out.data_ptr(), zp.data_ptr() if with_bs else None, bnp.data_ptr() if with_bs else None, part.data_ptr() if with_bs else None,
+              dz.data_ptr(), N, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref), (dz.float() - dz_ref.float()).abs().max()
+    assert torch.equal(out, out_ref), (out.float() - out_ref.float()).abs().max()
+    if with_bs:
+        assert torch.equal(part, part_ref)
+    # without the by-product store the data gradient is the same
+    out2 = torch.empty_like(out)
+    _lib.call('bdn_conv3x3_dgrad_bb', BDN_BF16, dA_d.data_ptr(), C0, z_d.data_ptr(), bn_d.data_ptr(), sums.data_ptr(), ipg, wd.data_ptr(),
+              out2.data_ptr(), None, None, None, None, N, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out_ref)
 
 
 # ------------------------------------------------------------------ weight gradient
