@@ -202,7 +202,7 @@ def mfma_ceiling():
 
 
 # ---------------------------------------------------------------------------------------------- where the step's time goes
-_CLASS_OF = {'bdn_conv3x3_dgrad_bs': 'conv_dgrad', 'bdn_conv3x3_wgrad_ex': 'wgrad', 'bdn_conv3x3_wgrad_bnbwd': 'wgrad',
+_CLASS_OF = {'bdn_conv3x3_dgrad_bs': 'conv_dgrad', 'bdn_conv3x3_dgrad_bb': 'conv_dgrad', 'bdn_conv3x3_wgrad_ex': 'wgrad', 'bdn_conv3x3_wgrad_bnbwd': 'wgrad',
              'bdn_bn_finalize': 'finalize', 'bdn_bn_bwd_finalize': 'finalize'}
 
 

@@ -528,9 +528,9 @@ static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     if (g_conv_query) {
         // the full template spelling, so that a profiler can match rocprofv3's kernel names exactly ("bf16" = unsigned short)
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s%s>",
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s>",
                  sizeof(T) == 2 ? "bf16" : "float", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false",
-                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? ",true" : "");
+                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false");
         return BDN_OK;
     }
     auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB>;

@@ -82,7 +82,7 @@ int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 const void* w, const float* bias, void* out, float* stats_partial,
                 int N, int H, int W, int Cout, void* stream);
 int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group);
-/* Name of the kernel instantiation bdn_conv3x3 runs for a shape, e.g. "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false>"
+/* Name of the kernel instantiation bdn_conv3x3 runs for a shape, e.g. "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false>"
  * (the rocprofv3 name with `unsigned short` spelled bf16); "" for an unsupported shape.  Thread-local buffer. */
 const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group);
 
