@@ -62,7 +62,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.bdn_conv3x3_variant(BDN_BF16X3, 128, 64, 64, 128, 0, 128, 64).endswith(b'float,false,false>')
     for name, args, msg in (
             ('bdn_conv3d', (BDN_BF16, None, 64, 0, None, 1, None, None, None, None, 1, 1, 8, 8, 64, None), 'null pointer'),
-            ('bdn_conv3d', (BDN_BF16X3, 1, 64, 0, None, 1, 1, None, 1, None, 1, 1, 8, 8, 64, None), 'bad dtype'),
+            ('bdn_conv3d', (7, 1, 64, 0, None, 1, 1, None, 1, None, 1, 1, 8, 8, 64, None), 'bad dtype'),
             ('bdn_conv3d', (BDN_BF16, 1, 60, 0, None, 1, 1, None, 1, None, 1, 1, 8, 8, 64, None), 'multiple'),
             ('bdn_conv3d_wgrad', (BDN_BF16, 1, 64, 1, 64, 1, 1, 80, 1, 1, 8, 8, None), 'Cin_real'),
             ('bdn_split_pack', (1, 12, None, 0, 0, None, 1, 1, 1, 8, 8, None), 'bad shape'),
