@@ -534,9 +534,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (MI355X); there is no CPU path for the product')
+    # BENCH_BACKEND=gloo (tests only): the N-rank code path of this file on a box with ONE device -- all ranks share cuda:0 and exchange
+    # gradients over gloo, exactly as tests/test_gpu_ddp.py does (RCCL refuses two ranks on one device)
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')
+    if backend == 'gloo':
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 and backend == 'gloo':
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    elif world > 1:
         from fabric_amd.parallel import init_rccl
         init_rccl(rank, world, dev)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'      # launch_plan() refused anything else
@@ -618,7 +626,7 @@ def main():
         torch.cuda.synchronize()
         w = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([w], dtype=torch.float64, device=dev)
+            t = torch.tensor([w], dtype=torch.float64, device=dev if backend != 'gloo' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w = float(t.item())
         windows.append(w)

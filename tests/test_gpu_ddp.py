@@ -232,3 +232,24 @@ def test_guard_recovers_the_slow_collective_stream_arrangement(tmp_path):
     if first > 0.05:                      # the slow state was there (it is on every box measured so far): a remedy must have been applied
         assert rep['recovered'] and any(rep['streams_replaced']) or rep['deferred_buckets'], rep
     print(f"slow arrangement {first * 100:+.1f} % -> {rep['overhead_frac'] * 100:+.1f} % after {[t['remedy'] for t in rep['tried']]}")
+
+
+def test_bench_two_ranks_end_to_end_on_one_device():
+    """bench.py's N > 1 code path for real: torch.distributed.run with two ranks (the driver's command line), both on cuda:0 with gloo
+    in place of RCCL (BENCH_BACKEND=gloo: the one thing a single-GPU box cannot do is give each rank its own device).  One JSON line
+    from rank 0 with n_gpus == 2, weak scaling, whole-job value = 2 ranks x batch x steps / window, three windows."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['BENCH_BACKEND'] = 'gloo'
+    port = str(36000 + os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', port,
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '8', '--size', '64']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 3 and len(d['windows_ms_per_step']) == 3
+    assert d['config']['global_batch'] == 16 and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 2 * 8 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value'] and d['value'] > 0
+    assert d['roofline'] is not None and d['step_classes'] is not None and 'cpu_baseline' not in d
