@@ -205,6 +205,11 @@ def main(argv=None):
     criterion = get_criterion(opt)                         # validation reports the criterion the run optimises (train.py:137)
     if fused:
         step = TrainStep(model, lr=opt.learning_rate, tversky_alpha=opt.tversky_alpha, tversky_beta=opt.tversky_beta)
+        if world > 1:
+            # measure (and, if it is the slow one, repair) the placement of RCCL's collective stream BEFORE the loop adopts the chain's stream
+            rep = step.guard_collectives(opt.batch_size, opt.patch_size, opt.patch_size)
+            if rank == 0:
+                print(json.dumps({'collectives_guard': rep}), flush=True)
     else:
         optimizer = torch.optim.SGD(model.parameters(), lr=opt.learning_rate)      # train.py:55
         if world > 1:
