@@ -74,6 +74,7 @@ SIGNATURES = {
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),
     'bdn_bn_bwd_finalize': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_bwd_apply': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bdn_bn_bwd_apply_split': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_overlap_loss': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_focal_workspace_bytes': (_sz, []),
     'bdn_focal': (_i, [_vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -342,11 +342,15 @@ extern "C" size_t bdn_bn_bwd_scratch_bytes(int G, int C) {
 }
 
 // dz = scale * (g - s0/M - xhat * s1/M)
-template <typename T>
+// SPLIT (float32 tensors, bf16x3 setting): dz is not stored as float32 but directly as the [hi | lo] bf16 operand its two consumers (the
+// data-gradient conv and the weight-gradient GEMM) take -- out [pixels][2 C] = hi(dz) | lo(dz), the layout of bdn_split_pack -- which
+// saves the separate split pass over dz (a float32 read + the same bytes written again) per layer.
+template <typename T, bool SPLIT = false>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* __restrict__ z, const float* __restrict__ bn,
                                     const float* __restrict__ sums, int pix_per_group, int blocks_per_group, int pix_per_block, int C,
                                     T* __restrict__ dz) {
     constexpr int EPU = ET<T>::EPU;
+    static_assert(!SPLIT || sizeof(T) == 4, "the split output belongs to the float32 setting");
     const int CU = C / EPU, rows = 256 / CU;
     const int g = blockIdx.x / blocks_per_group, bg = blockIdx.x % blocks_per_group;
     const int p_begin = bg * pix_per_block, p_end = min(pix_per_group, p_begin + pix_per_block);
@@ -371,7 +375,16 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* 
             const float xhat = (fz[i] - mean[i]) * inv[i];
             o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
         }
-        *reinterpret_cast<uint4*>(dz + pix * C + c) = Unit<T>::pack(o);
+        if constexpr (SPLIT) {
+            bf16s* out = reinterpret_cast<bf16s*>(dz);
+            const uint32_t h01 = f2bf2(o[0], o[1]), h23 = f2bf2(o[2], o[3]);
+            const uint32_t l01 = f2bf2(o[0] - bf2f(h01 & 0xffffu), o[1] - bf2f(h01 >> 16));      // exact differences in float32
+            const uint32_t l23 = f2bf2(o[2] - bf2f(h23 & 0xffffu), o[3] - bf2f(h23 >> 16));
+            *reinterpret_cast<uint2*>(out + pix * 2 * C + c) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(out + pix * 2 * C + C + c) = make_uint2(l01, l23);
+        } else {
+            *reinterpret_cast<uint4*>(dz + pix * C + c) = Unit<T>::pack(o);
+        }
     }
 }
 
@@ -413,7 +426,7 @@ static int bn_bwd_impl(const void* dA, int ldA, const void* z, const float* bn, 
     return BDN_OK;
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 static int bn_bwd_apply_impl(const void* dA, int ldA, const void* z, const float* bn, int imgs_per_group,
                              int N, int H, int W, int C, const float* partial, int rows_per_group, int raw_moment,
                              float* sums, float* dgamma, float* dbeta, void* dz, void* scratch, hipStream_t st) {
@@ -424,7 +437,7 @@ static int bn_bwd_apply_impl(const void* dA, int ldA, const void* z, const float
     const int bpg = (ppg + ppb - 1) / ppb;
     launch_bn_bwd_finalize(partial, rows_per_group, G, C, sums, dgamma, dbeta, raw_moment ? bn : (const float*)nullptr, scratch, st);
     BDN_CHECK_LAUNCH("bn_bwd_finalize");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(G * bpg), dim3(256), 0, st,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, SPLIT>), dim3(G * bpg), dim3(256), 0, st,
                        (const T*)dA, ldA, (const T*)z, bn, sums, ppg, bpg, ppb, C, (T*)dz);
     BDN_CHECK_LAUNCH("bn_bwd_apply");
     return BDN_OK;
@@ -441,6 +454,20 @@ extern "C" int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* 
     if (dtype == BDN_BF16) return bn_bwd_apply_impl<bf16s>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, scratch, (hipStream_t)stream);
     if (dtype == BDN_F32) return bn_bwd_apply_impl<float>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta, dz, scratch, (hipStream_t)stream);
     BDN_FAIL(BDN_E_ARG, "bn_bwd_apply: bad dtype");
+}
+
+// bf16x3 setting: as bdn_bn_bwd_apply on float32 tensors, but dz leaves as the split operand [N,H,W,2 C] bf16 = hi | lo (bdn_split_pack's
+// layout) that the data-gradient conv and the weight-gradient GEMM of the layer take: no float32 dz, no split pass over it.
+extern "C" int bdn_bn_bwd_apply_split(const void* dA, int ldA, const void* z, const float* bn,
+                                      int imgs_per_group, int N, int H, int W, int C,
+                                      const float* partial, int rows_per_group, int raw_moment,
+                                      float* sums, float* dgamma, float* dbeta, void* dz_split, void* scratch, void* stream) {
+    if (!dA || !z || !bn || !partial || !sums || !dz_split) BDN_FAIL(BDN_E_ARG, "bn_bwd_apply_split: null pointer");
+    if (N <= 0 || imgs_per_group <= 0 || N % imgs_per_group || C % 16 || ldA < C || ldA % 16 || rows_per_group <= 0)
+        BDN_FAIL(BDN_E_SHAPE, "bn_bwd_apply_split: bad shape");
+    if (C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "bn_bwd_apply_split: C=%d must divide 1024", C);
+    return bn_bwd_apply_impl<float, true>(dA, ldA, z, bn, imgs_per_group, N, H, W, C, partial, rows_per_group, raw_moment, sums, dgamma, dbeta,
+                                          dz_split, scratch, (hipStream_t)stream);
 }
 
 // The finalize step alone (partial rows -> sums / dgamma / dbeta): for a consumer that applies the backward itself

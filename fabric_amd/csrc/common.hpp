@@ -29,6 +29,9 @@ void bdn_set_error(const char* fmt, ...);
 
 // bf16x3 helpers defined in x3.hip, used by the dtype dispatch of bdn_pack_weights / bdn_conv3x3_wgrad_ex
 int bdn_pack_weights_x3(const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int Cin_pad, hipStream_t st);
+// bdn_pack_weights_multi's device record: one per layer
+struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, Cinp, pad_; };
+int bdn_pack_weights_x3_multi(const PackDesc* desc, int n_layers, hipStream_t st);
 int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, int taps, hipStream_t st);
 
 // ---------------------------------------------------------------- element traits

@@ -72,7 +72,6 @@ extern "C" int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* 
 }
 
 // all layers in one launch: desc[l] = {w, wf, wd, Cout, Cin, Cin_pad}; grid.y = layer
-struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, Cinp, pad_; };
 // one thread per OUTPUT element (coalesced 2/4-byte writes in fragment order; the strided reads of the
 // 54 MB fp32 master hit L2)
 template <typename T>
@@ -181,6 +180,7 @@ extern "C" int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers,
         hipLaunchKernelGGL(pack_weights_irregular_kernel, dim3(32, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
     }
     else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3(256, n_layers), dim3(256), 0, st, (const PackDesc*)desc);
+    else if (dtype == BDN_BF16X3) return bdn_pack_weights_x3_multi((const PackDesc*)desc, n_layers, st);      // images of 3x the reduction length (x3.hip)
     else BDN_FAIL(BDN_E_ARG, "pack_weights_multi: bad dtype");
     BDN_CHECK_LAUNCH("pack_weights_multi");
     return BDN_OK;

@@ -266,17 +266,19 @@ class BiDateEngine:
     def _pack_all(self, P):
         import struct
         if self.x3:
-            # split filter images, three times the reduction length: [w_hi | w_hi | w_lo] (csrc/x3.hip); one launch per layer
+            # split filter images, three times the reduction length: [w_hi | w_hi | w_lo] (csrc/x3.hip); all layers in one launch
             ptrs = tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)
             if self._pack_desc is None or self._pack_desc[0] != ptrs:
                 dev = P[f'{self.layers[0].conv}.weight'].device
-                self._packed = {L.conv: (torch.empty(L.cout, 9, 3 * L.cin, dtype=torch.bfloat16, device=dev),
-                                         torch.empty(L.cin, 9, 3 * L.cout, dtype=torch.bfloat16, device=dev) if L.name != 'e1a' else None)
-                                for L in self.layers}
-                self._pack_desc = (ptrs, None)
-            for L in self.layers:
-                wf, wd = self._packed[L.conv]
-                call('bdn_pack_weights', BDN_BF16X3, ptr(P[f'{L.conv}.weight']), ptr(wf), ptr(wd), L.cout, L.cin_real, L.cin, _lib.stream_ptr())
+                self._packed, rec = {}, b''
+                for L in self.layers:
+                    wf = torch.empty(L.cout, 9, 3 * L.cin, dtype=torch.bfloat16, device=dev)
+                    wd = torch.empty(L.cin, 9, 3 * L.cout, dtype=torch.bfloat16, device=dev) if L.name != 'e1a' else None
+                    self._packed[L.conv] = (wf, wd)
+                    rec += struct.pack('<QQQiiii', P[f'{L.conv}.weight'].data_ptr(), wf.data_ptr(),
+                                       wd.data_ptr() if wd is not None else 0, L.cout, L.cin_real, L.cin, 0)
+                self._pack_desc = (ptrs, torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev))
+            call('bdn_pack_weights_multi', BDN_BF16X3, ptr(self._pack_desc[1]), len(self.layers), _lib.stream_ptr())
             self._packed_versions = tuple(P[f'{L.conv}.weight']._version for L in self.layers)
             self._packed_valid = True
             return
@@ -444,6 +446,14 @@ class BiDateEngine:
             """BatchNorm+ReLU backward of layer L.  fused_rows > 0: the kernel that produced dA already left the
             per-tile partial sums (sum g, sum g*z) in ws.stats, fused_rows rows per statistic group."""
             hk, wk = ws.dims[L.level - 1]
+            if fused_rows and self.x3:
+                # bf16x3: dz leaves the pass as the [hi | lo] operand of its two consumers (per-layer buffer: the weight-gradient stream may
+                # lag a layer behind); there is no float32 dz and no split pass over it
+                sp = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)
+                call('bdn_bn_bwd_apply_split', dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
+                     ptr(ws.stats), fused_rows, 1, ptr(sc['sums']), ptr(grads[f'{L.bn}.weight']),
+                     ptr(grads[f'{L.bn}.bias']), ptr(sp), ptr(ws.bnws), st)
+                return None
             dz = e(n, hk, wk, L.cout)
             if fused_rows:
                 call('bdn_bn_bwd_apply', self.dt, dA, ldA, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ipg, n, hk, wk, L.cout,
@@ -537,8 +547,8 @@ class BiDateEngine:
             return sp
 
         def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
-            if self.x3:
-                split_dz(L, dz, n, ipg)              # on the chain's stream, before the hand-off below
+            if self.x3 and dz is not None:
+                split_dz(L, dz, n, ipg)              # on the chain's stream, before the hand-off below (bn_bwd already left the split otherwise)
             if self._diag_skip_wgrad:                # tools/ab_step.py diagnostic only: how long is the dz chain alone?
                 return
             hk, wk = ws.dims[L.level - 1]

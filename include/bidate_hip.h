@@ -63,7 +63,8 @@ int bdn_pack_weights(int dtype, const float* w_oihw, void* wf, void* wd,
                      int Cout, int Cin, int Cin_pad, void* stream);
 
 /* The same for n_layers filters in one launch.  desc: DEVICE array of n_layers records
- * { const float* w_oihw; void* wf; void* wd; int32 Cout, Cin, Cin_pad, reserved; } (40 bytes each). */
+ * { const float* w_oihw; void* wf; void* wd; int32 Cout, Cin, Cin_pad, reserved; } (40 bytes each).  dtype BDN_BF16X3: the split images of
+ * bdn_pack_weights(BDN_BF16X3) for every record. */
 int bdn_pack_weights_multi(int dtype, const void* desc, int n_layers, void* stream);
 
 /* ---- 3x3 convolution, stride 1, zero padding 1: nn.Conv2d(ci,co,3,padding=1), models/unet_parts.py:13,16 ----
@@ -217,6 +218,12 @@ int bdn_bn_bwd_apply(int dtype, const void* dA, int ldA, const void* z, const fl
                      int imgs_per_group, int N, int H, int W, int C,
                      const float* partial, int rows_per_group, int raw_moment,
                      float* sums, float* dgamma, float* dbeta, void* dz, void* scratch, void* stream);
+/* bf16x3 setting (float32 tensors): the same, with dz stored directly as the split operand of its two consumers -- dz_split
+ * [N,H,W,2 C] bf16 = hi(dz) | lo(dz), bdn_split_pack's layout -- instead of float32: no bdn_split_pack pass over dz. */
+int bdn_bn_bwd_apply_split(const void* dA, int ldA, const void* z, const float* bn,
+                           int imgs_per_group, int N, int H, int W, int C,
+                           const float* partial, int rows_per_group, int raw_moment,
+                           float* sums, float* dgamma, float* dbeta, void* dz_split, void* scratch, void* stream);
 /* The reduction half of bdn_bn_bwd_apply alone: partial rows -> sums [G][2][C], dgamma, dbeta (same argument meaning),
  * for a consumer that applies the backward while it stages dz (bdn_conv3x3_wgrad_bnbwd). */
 int bdn_bn_bwd_finalize(const float* bn, int G, int C, const float* partial, int rows_per_group, int raw_moment,
