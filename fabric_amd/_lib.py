@@ -56,6 +56,8 @@ SIGNATURES = {
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_product_pool': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'bdn_product_pool_split': (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_upsample2x_split': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_bwd_rows': (_i, [_i, _i, _i, _i, _i]),
     'bdn_upsample2x_bwd_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

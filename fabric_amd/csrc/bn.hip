@@ -376,12 +376,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dA, int ldA, const T* 
             o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
         }
         if constexpr (SPLIT) {
-            bf16s* out = reinterpret_cast<bf16s*>(dz);
-            const uint32_t h01 = f2bf2(o[0], o[1]), h23 = f2bf2(o[2], o[3]);
-            const uint32_t l01 = f2bf2(o[0] - bf2f(h01 & 0xffffu), o[1] - bf2f(h01 >> 16));      // exact differences in float32
-            const uint32_t l23 = f2bf2(o[2] - bf2f(h23 & 0xffffu), o[3] - bf2f(h23 >> 16));
-            *reinterpret_cast<uint2*>(out + pix * 2 * C + c) = make_uint2(h01, h23);
-            *reinterpret_cast<uint2*>(out + pix * 2 * C + C + c) = make_uint2(l01, l23);
+            const SplitOut so = {reinterpret_cast<bf16s*>(dz), 2 * C, 0, C};
+            store_split4(so, pix, c, o);
         } else {
             *reinterpret_cast<uint4*>(dz + pix * C + c) = Unit<T>::pack(o);
         }

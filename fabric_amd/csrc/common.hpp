@@ -84,6 +84,29 @@ template <> struct Unit<bf16s> {
     }
 };
 
+// bf16x3: a float32 kernel's output stored directly as the [hi | lo] bf16 operand of the convolution that consumes it (bdn_split_pack's
+// layout, possibly a channel window of a wider two-source operand): [pixel][ld], hi at off + c, lo at half + off + c.  p == nullptr: off.
+struct SplitOut { bf16s* p; int ld, off, half; };
+__device__ __forceinline__ void store_split4(const SplitOut& so, size_t pix, int c, const float* o_) {
+    // the values are pinned first: without it the compiler contracts the product that formed o with the subtraction below into one FMA,
+    // and lo would be the residual of the UNROUNDED product (not what splitting the stored float32 tensor gives)
+    float o[4] = {o_[0], o_[1], o_[2], o_[3]};
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+    const uint32_t h01 = f2bf2(o[0], o[1]), h23 = f2bf2(o[2], o[3]);
+    const uint32_t l01 = f2bf2(o[0] - bf2f(h01 & 0xffffu), o[1] - bf2f(h01 >> 16));      // exact differences in float32
+    const uint32_t l23 = f2bf2(o[2] - bf2f(h23 & 0xffffu), o[3] - bf2f(h23 >> 16));
+    *reinterpret_cast<uint2*>(so.p + pix * so.ld + so.off + c) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(so.p + pix * so.ld + so.half + so.off + c) = make_uint2(l01, l23);
+}
+// store 16 bytes of output: as T at dst, or (float32 only) as the split pair when so.p is set
+template <typename T>
+__device__ __forceinline__ void store_out(T* dst_base, size_t elem_index, const SplitOut& so, size_t pix, int c, const float* o) {
+    if constexpr (sizeof(T) == 4) {
+        if (so.p) { store_split4(so, pix, c, o); return; }
+    }
+    *reinterpret_cast<uint4*>(dst_base + elem_index) = Unit<T>::pack(o);
+}
+
 // BatchNorm table layout: bn[g][k][c], k = 0 mean, 1 invstd, 2 scale, 3 shift
 __device__ __forceinline__ const float* bn_row(const float* bn, int g, int k, int C) {
     return bn + ((size_t)g * 4 + k) * C;

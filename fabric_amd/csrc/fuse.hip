@@ -138,7 +138,7 @@ extern "C" int bdn_fuse_product(int dtype, const void* z, const float* bn, void*
 // iteration = one 2x2 window x EPU channels x both dates, so z is read from HBM once instead of twice.
 template <typename T>
 __global__ void product_pool_kernel(const T* __restrict__ z, const float* __restrict__ bn, T* __restrict__ f, T* __restrict__ pool,
-                                    int B, int H, int W, int C, int ncell) {
+                                    int B, int H, int W, int C, int ncell, SplitOut sf, SplitOut sp) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
@@ -166,29 +166,47 @@ __global__ void product_pool_kernel(const T* __restrict__ z, const float* __rest
                     m0[i] = fmaxf(m0[i], a0[i]); m1[i] = fmaxf(m1[i], a1[i]);
                     a0[i] *= a1[i];                                         // >= 0: relu is a no-op
                 }
-                *reinterpret_cast<uint4*>(f + p0 * C + c) = Unit<T>::pack(a0);
+                store_out<T>(f, p0 * C + c, sf, p0, c, a0);
             }
         }
         if (yc < Ho && xc < Wo) {                                           // floor-mode pooling drops a trailing odd row / column
-            *reinterpret_cast<uint4*>(pool + ((size_t)(b * Ho + yc) * Wo + xc) * C + c) = Unit<T>::pack(m0);
-            *reinterpret_cast<uint4*>(pool + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c) = Unit<T>::pack(m1);
+            const size_t q0 = (size_t)(b * Ho + yc) * Wo + xc, q1 = (size_t)((B + b) * Ho + yc) * Wo + xc;
+            store_out<T>(pool, q0 * C + c, sp, q0, c, m0);
+            store_out<T>(pool, q1 * C + c, sp, q1, c, m1);
         }
     }
+}
+
+static int product_pool_impl(int dtype, const void* z, const float* bn, void* f, void* pool, SplitOut sf, SplitOut sp,
+                             int B, int H, int W, int C, void* stream) {
+    if (C % 16 || C > 1024 || 1024 % C || H < 2 || W < 2) BDN_FAIL(BDN_E_SHAPE, "product_pool: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
+    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
+        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell, sf, sp); }
+    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
+        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell, sf, sp); }
+    else BDN_FAIL(BDN_E_ARG, "product_pool: bad dtype");
+    BDN_CHECK_LAUNCH("product_pool");
+    return BDN_OK;
 }
 
 extern "C" int bdn_product_pool(int dtype, const void* z, const float* bn, void* f, void* pool,
                                 int B, int H, int W, int C, void* stream) {
     if (!z || !bn || !f || !pool) BDN_FAIL(BDN_E_ARG, "product_pool: null pointer");
-    if (C % 16 || C > 1024 || 1024 % C || H < 2 || W < 2) BDN_FAIL(BDN_E_SHAPE, "product_pool: bad shape");
-    hipStream_t st = (hipStream_t)stream;
-    const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
-    if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
-        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell); }
-    else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
-        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell); }
-    else BDN_FAIL(BDN_E_ARG, "product_pool: bad dtype");
-    BDN_CHECK_LAUNCH("product_pool");
-    return BDN_OK;
+    const SplitOut none = {nullptr, 0, 0, 0};
+    return product_pool_impl(dtype, z, bn, f, pool, none, none, B, H, W, C, stream);
+}
+
+// bf16x3 setting: both outputs leave as the [hi | lo] bf16 operands of the convolutions that consume them -- f into channels [0, C) of the
+// decoder stage's two-source operand [B,H,W,f_ld] (lo half at f_half), pool as [2B,H/2,W/2,2C] -- instead of float32 tensors that a
+// bdn_split_pack pass would read again.  z float32.
+extern "C" int bdn_product_pool_split(const void* z, const float* bn, void* f_split, int f_ld, int f_half, void* pool_split,
+                                      int B, int H, int W, int C, void* stream) {
+    if (!z || !bn || !f_split || !pool_split) BDN_FAIL(BDN_E_ARG, "product_pool_split: null pointer");
+    if (f_half < C || f_ld < f_half + C || f_ld % 8 || f_half % 8) BDN_FAIL(BDN_E_SHAPE, "product_pool_split: bad operand layout ld=%d half=%d", f_ld, f_half);
+    const SplitOut sf = {(bf16s*)f_split, f_ld, 0, f_half}, sp = {(bf16s*)pool_split, 2 * C, 0, C};
+    return product_pool_impl(BDN_F32, z, bn, nullptr, nullptr, sf, sp, B, H, W, C, stream);
 }
 
 // ============================================================ bilinear x2 (align_corners=True) + F.pad
@@ -203,7 +221,7 @@ static inline float up_scale(int n_in) { return n_in > 1 ? (float)(n_in - 1) / (
 
 template <typename T>
 __global__ void upsample2x_kernel(const T* __restrict__ src, const float* __restrict__ bn, T* __restrict__ out,
-                                  int npix, int h, int w, int H, int W, int C, float sy, float sx) {
+                                  int npix, int h, int w, int H, int W, int C, float sy, float sx, SplitOut so) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int top = (H - 2 * h) / 2, left = (W - 2 * w) / 2;
@@ -229,7 +247,7 @@ __global__ void upsample2x_kernel(const T* __restrict__ src, const float* __rest
                 for (int i = 0; i < EPU; i++) o[i] += wgt * (bn ? act1<T>(f[i], sc[i], sh[i]) : f[i]);
             }
         }
-        *reinterpret_cast<uint4*>(out + (size_t)p * C + c) = Unit<T>::pack(o);
+        store_out<T>(out, (size_t)p * C + c, so, (size_t)p, c, o);
     }
 }
 
@@ -239,7 +257,7 @@ __global__ void upsample2x_kernel(const T* __restrict__ src, const float* __rest
 // VALU-bound at 1.8 TB/s), then each thread blends four outputs from LDS with the same tap order and weights.
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_tiled_kernel(const T* __restrict__ src, const float* __restrict__ bn, T* __restrict__ out,
-                                                             int h, int w, int H, int W, int C, int tiles_x, int tiles_y, float sy, float sx) {
+                                                             int h, int w, int H, int W, int C, int tiles_x, int tiles_y, float sy, float sx, SplitOut so) {
     constexpr int EPU = ET<T>::EPU, TO = 16, RS = 10, UB = 4, PSTR = UB * 16 + 16;
     __shared__ __attribute__((aligned(16))) unsigned char sm[RS * RS * PSTR];
     const int tid = threadIdx.x;
@@ -287,13 +305,12 @@ __global__ __launch_bounds__(256) void upsample2x_tiled_kernel(const T* __restri
                 for (int i = 0; i < EPU; i++) o[i] += wgt * f[i];
             }
         }
-        *reinterpret_cast<uint4*>(out + ((size_t)(n * H + Y) * W + X) * C + c0 + uu * EPU) = Unit<T>::pack(o);
+        { const size_t pp = (size_t)(n * H + Y) * W + X; store_out<T>(out, pp * C + c0 + uu * EPU, so, pp, c0 + uu * EPU, o); }
     }
 }
 
-extern "C" int bdn_upsample2x(int dtype, const void* src, int in_mode, const float* bn,
-                              void* out, int B, int h, int w, int H, int W, int C, void* stream) {
-    if (!src || !out) BDN_FAIL(BDN_E_ARG, "upsample2x: null pointer");
+static int upsample2x_impl(int dtype, const void* src, int in_mode, const float* bn,
+                           void* out, SplitOut so, int B, int h, int w, int H, int W, int C, void* stream) {
     if (in_mode == BDN_IN_BNRELU && !bn) BDN_FAIL(BDN_E_ARG, "upsample2x: BNRELU needs bn");
     if (H < 2 * h || W < 2 * w || C % 16 || C > 1024 || 1024 % C) BDN_FAIL(BDN_E_SHAPE, "upsample2x: bad shape");
     const float* b = in_mode == BDN_IN_BNRELU ? bn : nullptr;
@@ -304,18 +321,36 @@ extern "C" int bdn_upsample2x(int dtype, const void* src, int in_mode, const flo
     if (h >= 8 && w >= 8 && C % (4 * epu) == 0 && (dtype == BDN_BF16 || dtype == BDN_F32)) {
         const int tx = (W + 15) / 16, ty = (H + 15) / 16;
         const dim3 grid(tx * ty * B, C / (4 * epu));
-        if (dtype == BDN_BF16) hipLaunchKernelGGL(upsample2x_tiled_kernel<bf16s>, grid, dim3(256), 0, st, (const bf16s*)src, b, (bf16s*)out, h, w, H, W, C, tx, ty, sy, sx);
-        else hipLaunchKernelGGL(upsample2x_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)src, b, (float*)out, h, w, H, W, C, tx, ty, sy, sx);
+        if (dtype == BDN_BF16) hipLaunchKernelGGL(upsample2x_tiled_kernel<bf16s>, grid, dim3(256), 0, st, (const bf16s*)src, b, (bf16s*)out, h, w, H, W, C, tx, ty, sy, sx, so);
+        else hipLaunchKernelGGL(upsample2x_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)src, b, (float*)out, h, w, H, W, C, tx, ty, sy, sx, so);
         BDN_CHECK_LAUNCH("upsample2x_tiled");
         return BDN_OK;
     }
     if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * ITERS;
-        hipLaunchKernelGGL(upsample2x_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)src, b, (bf16s*)out, npix, h, w, H, W, C, sy, sx); }
+        hipLaunchKernelGGL(upsample2x_kernel<bf16s>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const bf16s*)src, b, (bf16s*)out, npix, h, w, H, W, C, sy, sx, so); }
     else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * ITERS;
-        hipLaunchKernelGGL(upsample2x_kernel<float>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const float*)src, b, (float*)out, npix, h, w, H, W, C, sy, sx); }
+        hipLaunchKernelGGL(upsample2x_kernel<float>, dim3((npix + per - 1) / per), dim3(256), 0, st, (const float*)src, b, (float*)out, npix, h, w, H, W, C, sy, sx, so); }
     else BDN_FAIL(BDN_E_ARG, "upsample2x: bad dtype");
     BDN_CHECK_LAUNCH("upsample2x");
     return BDN_OK;
+}
+
+extern "C" int bdn_upsample2x(int dtype, const void* src, int in_mode, const float* bn,
+                              void* out, int B, int h, int w, int H, int W, int C, void* stream) {
+    if (!src || !out) BDN_FAIL(BDN_E_ARG, "upsample2x: null pointer");
+    const SplitOut none = {nullptr, 0, 0, 0};
+    return upsample2x_impl(dtype, src, in_mode, bn, out, none, B, h, w, H, W, C, stream);
+}
+
+// bf16x3 setting: the upsampled map leaves as channels [off, off + C) of the decoder stage's [hi | lo] two-source operand
+// out_split [B,H,W,ld] bf16 (lo half at `half`) instead of a float32 tensor that bdn_split_pack would read again.  src float32.
+extern "C" int bdn_upsample2x_split(const void* src, int in_mode, const float* bn, void* out_split, int ld, int off, int half,
+                                    int B, int h, int w, int H, int W, int C, void* stream) {
+    if (!src || !out_split) BDN_FAIL(BDN_E_ARG, "upsample2x_split: null pointer");
+    if (off < 0 || off % 8 || half < off + C || ld < half + off + C || ld % 8 || half % 8)
+        BDN_FAIL(BDN_E_SHAPE, "upsample2x_split: bad operand layout ld=%d off=%d half=%d", ld, off, half);
+    const SplitOut so = {(bf16s*)out_split, ld, off, half};
+    return upsample2x_impl(BDN_F32, src, in_mode, bn, nullptr, so, B, h, w, H, W, C, stream);
 }
 
 // transpose: every source pixel gathers from the destination rows / columns that read it

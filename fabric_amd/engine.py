@@ -309,7 +309,7 @@ class BiDateEngine:
                 if not ws.leased:
                     ws.release_split()
 
-    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st, reuse_eval_bn=False):
+    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st, reuse_eval_bn=False, presplit=False):
         hk, wk = ws.dims[L.level - 1]
         wf, _ = self._weights(L, P, False)
         z = ws.z[L.name]
@@ -317,7 +317,8 @@ class BiDateEngine:
             # the operand split does the cat and the BatchNorm+ReLU the f32 kernel would apply on load
             # training: one buffer per layer, kept for the layer's weight-gradient GEMM (the same operand: no second split in backward)
             sp = ws.split_buf(('a', L.name) if training else 'a', n * hk * wk * 2 * (c0 + c1))
-            call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
+            if not presplit:                         # presplit: the producers of the operand (product_pool / upsample2x) stored it split already
+                call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
             in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
         self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
                          self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
@@ -394,9 +395,15 @@ class BiDateEngine:
             hk, wk = ws.dims[k - 1]
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
             src = ws.x0 if k == 1 else ws.pool[k]           # pool[k] was written together with the skip of level k-1
-            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb)
+            pre = self.x3 and training                      # bf16x3 training: pooled maps, skips and upsampled maps are stored as split operands
+            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb, presplit=pre and k > 1)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st, rb)
-            if k < 5:                                       # skip f_k and the pooled input of level k+1 in one pass over z
+            if k < 5 and pre:
+                Ld, Ln = by[f'd{5 - k}a'], by[f'e{k + 1}a']
+                hn, wn = ws.dims[k]
+                call('bdn_product_pool_split', ptr(zb), ptr(bnb), ptr(ws.split_buf(('a', Ld.name), B * hk * wk * 2 * Ld.cin)), 2 * Ld.cin, Ld.cin,
+                     ptr(ws.split_buf(('a', Ln.name), 2 * B * hn * wn * 2 * Ln.cin)), B, hk, wk, ENC_CH[k - 1], st)
+            elif k < 5:                                     # skip f_k and the pooled input of level k+1 in one pass over z
                 call('bdn_product_pool', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), ptr(ws.pool[k + 1]), B, hk, wk, ENC_CH[k - 1], st)
             else:
                 call('bdn_fuse_product', self.dt, ptr(zb), ptr(bnb), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], st)
@@ -407,9 +414,14 @@ class BiDateEngine:
             hk, wk = ws.dims[k - 1]
             hs, wsrc = ws.dims[k]
             La, Lb = by[f'd{j}a'], by[f'd{j}b']
-            call('bdn_upsample2x', self.dt, ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.U[j]),
-                 B, hs, wsrc, hk, wk, cprev, st)
-            za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st, rb)
+            pre = self.x3 and training
+            if pre:
+                call('bdn_upsample2x_split', ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.split_buf(('a', La.name), B * hk * wk * 2 * La.cin)),
+                     2 * La.cin, ENC_CH[k - 1], La.cin, B, hs, wsrc, hk, wk, cprev, st)
+            else:
+                call('bdn_upsample2x', self.dt, ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.U[j]),
+                     B, hs, wsrc, hk, wk, cprev, st)
+            za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st, rb, presplit=pre)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st, rb)
             prev, prev_bn, prev_mode, cprev = zb, bnb, IN_BNRELU, Lb.cout
         logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)

@@ -246,11 +246,21 @@ int bdn_fuse_product(int dtype, const void* z, const float* bn, void* f,
 int bdn_product_pool(int dtype, const void* z, const float* bn, void* f, void* pool,
                      int B, int H, int W, int C, void* stream);
 
+/* bf16x3 setting (float32 z): both outputs stored directly as the [hi | lo] bf16 operands of the convolutions that consume them -- f into
+ * channels [0, C) of the decoder stage's two-source operand f_split [B,H,W,f_ld] (lo half f_half channels further), pool as
+ * pool_split [2B,H/2,W/2,2C] -- bdn_split_pack's layout, without the float32 tensors and the split pass over them. */
+int bdn_product_pool_split(const void* z, const float* bn, void* f_split, int f_ld, int f_half, void* pool_split,
+                           int B, int H, int W, int C, void* stream);
+
 /* ---- nn.Upsample(scale_factor=2, bilinear, align_corners=True) + F.pad: models/unet_parts.py:56-58,68-72 ----
  * src: [B,h,w,C] (plain, or raw z with bn when in_mode = BDN_IN_BNRELU); out: [B,H,W,C] with the
  * 2h x 2w map placed at offset ((H-2h)/2, (W-2w)/2) and zeros elsewhere. */
 int bdn_upsample2x(int dtype, const void* src, int in_mode, const float* bn,
                    void* out, int B, int h, int w, int H, int W, int C, void* stream);
+/* bf16x3 setting (float32 src): the upsampled map stored as channels [off, off + C) of the decoder stage's split operand
+ * out_split [B,H,W,ld] bf16 (lo half `half` channels further). */
+int bdn_upsample2x_split(const void* src, int in_mode, const float* bn, void* out_split, int ld, int off, int half,
+                         int B, int h, int w, int H, int W, int C, void* stream);
 /* Transpose of the above: dU: [B,H,W,ldU] channel slice -> dsrc: [B,h,w,C]. */
 int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
                        int B, int h, int w, int H, int W, int C, void* stream);

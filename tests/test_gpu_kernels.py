@@ -965,3 +965,52 @@ def test_conv3x3_bf16x3_forward_dgrad_wgrad(case):
               part.data_ptr(), dw.data_ptr(), Cin, N, H, W, st())
     torch.cuda.synchronize()
     assert_close('x3 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz, padding=1), 1e-4)
+
+
+def test_split_outputs_of_the_bf16x3_producers_equal_split_pack():
+    """bf16x3 setting: bdn_product_pool_split / bdn_upsample2x_split / bdn_bn_bwd_apply_split store their float32 results directly as
+    the [hi | lo] bf16 operands of the consuming GEMMs; each must equal bdn_split_pack of the float32 kernel's output bit for bit."""
+    from fabric_amd._lib import BDN_F32
+    B, H, W, C, Cu = 2, 24, 20, 64, 128
+    z = _rand((2 * B, C, H, W), 81)
+    bn = bn_table(2, C, 82)
+    z_d, bn_d = to_nhwc('fp32', z), dev(bn)
+    f = torch.empty(B, H, W, C, device='cuda'); pool = torch.empty(2 * B, H // 2, W // 2, C, device='cuda')
+    _lib.call('bdn_product_pool', BDN_F32, z_d.data_ptr(), bn_d.data_ptr(), f.data_ptr(), pool.data_ptr(), B, H, W, C, st())
+    # upsampled map of a (B, H/2, W/2, Cu) source with BatchNorm+ReLU on load: second source of the decoder operand [f | U]
+    src = to_nhwc('fp32', _rand((B, Cu, H // 2, W // 2), 83)); bnu = dev(bn_table(1, Cu, 84))
+    U = torch.empty(B, H, W, Cu, device='cuda')
+    _lib.call('bdn_upsample2x', BDN_F32, src.data_ptr(), IN_BNRELU, bnu.data_ptr(), U.data_ptr(), B, H // 2, W // 2, H, W, Cu, st())
+    Ct = C + Cu
+    ref_cat = torch.empty(B, H, W, 2 * Ct, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', f.data_ptr(), C, U.data_ptr(), Cu, IN_PLAIN, None, B, ref_cat.data_ptr(), B, H, W, st())
+    ref_pool = torch.empty(2 * B, H // 2, W // 2, 2 * C, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', pool.data_ptr(), C, None, 0, IN_PLAIN, None, B, ref_pool.data_ptr(), 2 * B, H // 2, W // 2, st())
+    got_cat = torch.zeros_like(ref_cat); got_pool = torch.zeros_like(ref_pool)
+    _lib.call('bdn_product_pool_split', z_d.data_ptr(), bn_d.data_ptr(), got_cat.data_ptr(), 2 * Ct, Ct, got_pool.data_ptr(), B, H, W, C, st())
+    _lib.call('bdn_upsample2x_split', src.data_ptr(), IN_BNRELU, bnu.data_ptr(), got_cat.data_ptr(), 2 * Ct, C, Ct, B, H // 2, W // 2, H, W, Cu, st())
+    torch.cuda.synchronize()
+    assert torch.equal(got_pool, ref_pool)
+    assert torch.equal(got_cat, ref_cat)
+    # BatchNorm backward with the split dz
+    lib = _lib.load()
+    N, ipg = 2 * B, B
+    dA = to_nhwc('fp32', _rand((N, C, H, W), 85))
+    ws = torch.empty(lib.bdn_bn_bwd_workspace_bytes(BDN_F32, N, H, W, C, ipg) // 4, device='cuda')
+    sums = torch.empty(2, 2, C, device='cuda'); dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    dz = torch.empty(N, H, W, C, device='cuda')
+    _lib.call('bdn_bn_bwd', BDN_F32, dA.data_ptr(), C, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, C, ws.data_ptr(), sums.data_ptr(), dg.data_ptr(),
+              db.data_ptr(), dz.data_ptr(), st())
+    ref_dz = torch.empty(N, H, W, 2 * C, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', dz.data_ptr(), C, None, 0, IN_PLAIN, None, ipg, ref_dz.data_ptr(), N, H, W, st())
+    # the same partial rows the fused producers would leave: one row per group holding the finalized sums is not available here, so feed
+    # the reduction's own block partials (raw_moment = 0: second moment already against xhat)
+    G = N // ipg
+    rows = (ws.numel() * 4 - lib.bdn_bn_bwd_scratch_bytes(G, C)) // (2 * C * 4) // G
+    sums2 = torch.empty_like(sums); got_dz = torch.zeros_like(ref_dz)
+    scratch = torch.empty(max(lib.bdn_bn_bwd_scratch_bytes(G, C) // 8, 1), dtype=torch.float64, device='cuda')
+    _lib.call('bdn_bn_bwd_apply_split', dA.data_ptr(), C, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, C, ws.data_ptr(), rows, 0,
+              sums2.data_ptr(), dg.data_ptr(), db.data_ptr(), got_dz.data_ptr(), scratch.data_ptr(), st())
+    torch.cuda.synchronize()
+    assert torch.equal(sums2, sums)
+    assert torch.equal(got_dz, ref_dz)
