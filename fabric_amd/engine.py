@@ -242,12 +242,12 @@ class BiDateEngine:
         from . import streams
         return streams.get('wgrad', device)
 
-    def workspace(self, B, H, W, device):
+    def workspace(self, B, H, W, device, slot=0):
         """A workspace of this shape that no live autograd graph owns (models/bidate_model.py leases the one its forward
         filled until the graph dies): a second forward of the same shape before backward() -- two micro-batches summed into
         one loss, a validation forward between forward and backward -- gets its own buffers instead of overwriting the
         activations the first graph's backward will read.  The fused TrainStep never leases, so it keeps one workspace."""
-        key = (B, H, W, str(device))
+        key = (B, H, W, str(device), slot)      # slot: independent forward streams of one shape (scene inference on two streams)
         pool = self._ws.setdefault(key, [])
         for ws in pool:
             if not ws.leased:
@@ -355,7 +355,7 @@ class BiDateEngine:
         call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, _lib.stream_ptr())
         return self._forward_packed(ws, P, training), ws
 
-    def forward_tiles(self, scene_d1, scene_d2, origins, P, patch_size, reuse_eval_bn=False):
+    def forward_tiles(self, scene_d1, scene_d2, origins, P, patch_size, reuse_eval_bn=False, slot=0):
         """Eval-mode forward of the tiles at `origins` (device int32 [n,2] = (y0,x0)) of a scene whose two dates
         are resident as [C,H,W] float32 band planes (train.py:190-197 without the host-side patch stack).
         reuse_eval_bn: the BatchNorm tables of this workspace are already those of P's running statistics.
@@ -370,7 +370,7 @@ class BiDateEngine:
             raise RuntimeError('scene planes and origins must be contiguous')
         C, H, W = scene_d1.shape
         n, p = origins.shape[0], patch_size
-        ws = self.workspace(n, p, p, scene_d1.device)
+        ws = self.workspace(n, p, p, scene_d1.device, slot)
         ws.generation += 1
         call('bdn_gather_tiles', self.dt, ptr(scene_d1), ptr(scene_d2), ptr(origins), ptr(ws.x0),
              n, C, H, W, p, self.cp, _lib.stream_ptr())

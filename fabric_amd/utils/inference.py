@@ -115,7 +115,7 @@ def predict_patches(model, patches1, patches2, batch_size, device='cuda'):
 
 
 @torch.no_grad()
-def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shard=None, merge=True, band_rows=None):
+def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shard=None, merge=True, band_rows=None, two_streams=True):
     """Change mask of a whole scene.
 
     scene_d1, scene_d2: [C,H,W] float32 tensors (what the reference's city_loader returns per date,
@@ -160,19 +160,34 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
     origins = torch.from_numpy(o_np).to(dev)
     mask = torch.zeros(h, w, dtype=torch.uint8, device=dev) if shard is not None \
         else torch.empty(h, w, dtype=torch.uint8, device=dev)
-    seen = set()
-    st = _lib.stream_ptr()
+    # Tile batches are independent: they alternate between the caller's stream and the library's second stream (idle outside training),
+    # each with its own workspace, so that one batch's HBM-bound stages (tile gather, pooling, upsampling, classifier, stitching) run
+    # under the other's convolutions.  two_streams=False: the single-stream loop.
+    from .. import streams as _streams
+    cur = torch.cuda.current_stream(dev)
+    lanes = [cur, _streams.get('wgrad', dev)] if two_streams and (hi - lo) > batch_size else [cur]
+    seen = [set() for _ in lanes]
+    if len(lanes) > 1:
+        eng._weights(eng.layers[0], P, False)            # the filter images are packed once, on the caller's stream, before the fork
+        lanes[1].wait_stream(cur)
+        for t in (d1, d2, mask, origins):
+            t.record_stream(lanes[1])
     try:
-        for i in range(lo, hi, batch_size):
+        for it, i in enumerate(range(lo, hi, batch_size)):
             j = min(hi, i + batch_size)
             o = origins[i:j]
             nb = o.shape[0]
-            if feed is not None:
-                feed.need_rows(int(o_np[i:j, 0].max()) + patch_size)       # the current stream waits for the last band these tiles read
-            logits, _ = eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen)
-            seen.add(nb)
-            call('bdn_argmax_stitch', ptr(logits), ptr(o), ptr(mask), nb, logits.shape[1], patch_size, h, w, st)
+            k = it % len(lanes)
+            with torch.cuda.stream(lanes[k]):
+                if feed is not None:
+                    feed.need_rows(int(o_np[i:j, 0].max()) + patch_size, lanes[k])     # this lane waits for the last band these tiles read
+                logits, _ = eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen[k], slot=k)
+                seen[k].add(nb)
+                call('bdn_argmax_stitch', ptr(logits), ptr(o), ptr(mask), nb, logits.shape[1], patch_size, h, w, lanes[k].cuda_stream)
+                logits.record_stream(lanes[k])
     finally:
+        for ln in lanes[1:]:
+            cur.wait_stream(ln)
         if feed is not None:
             feed.close()          # also on an exception: the consumer stream joins every upload before the planes can be freed
     if shard is not None and merge and shard[1] > 1:
@@ -207,7 +222,7 @@ class _SceneFeeder:
             alloc.record(self.copy)
         self.copy2.wait_event(alloc)          # d2 came from the copy stream's pool: whatever that stream still has queued on the block
         self.d2.record_stream(self.copy2)     # (a feeder that just closed) precedes copy2's writes, and the block is not re-used under them
-        self.events, self.waited, self.issued = [], -1, 0
+        self.events, self.waited, self.issued = [], {}, 0
         self.nbands = -(-H // band_rows)
         self.pinned = all(t.is_pinned() for t in self.src)
         self.pool = None if self.pinned else ThreadPoolExecutor(max_workers=8)
@@ -249,14 +264,17 @@ class _SceneFeeder:
                 self.stage_free[k % 2] = ev
             self.issued += 1
 
-    def need_rows(self, rows):
-        """Make the consumer stream wait until scene rows [0, rows) have arrived (and keep the copy stream LOOKAHEAD bands ahead)."""
+    def need_rows(self, rows, stream=None):
+        """Make the consumer stream (default: the one the feeder was created under) wait until scene rows [0, rows) have arrived, and keep
+        the copy stream LOOKAHEAD bands ahead.  Every consumer stream keeps its own high-water mark."""
         k = min(self.nbands - 1, (min(rows, self.H) - 1) // self.R)
         self._issue(k + self.LOOKAHEAD)
-        if k > self.waited:
+        stream = stream or self.cur
+        key = stream.cuda_stream
+        if k > self.waited.get(key, -1):
             for e_ in self.events[k]:                    # bands are uploaded in order on each stream: band k implies 0..k
-                self.cur.wait_event(e_)
-            self.waited = k
+                stream.wait_event(e_)
+            self.waited[key] = k
 
     def close(self):
         try:
