@@ -141,7 +141,7 @@ def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, pre
         model(y1, y2)                                   # a validation forward of the same shape between forward and backward
     model.train()
     lb = _tversky_torch(model(y1, y2), lb2)
-    assert len(model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device))]) == 2
+    assert len(model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device), 0)]) == 2
     (la + lb).backward()
     torch.cuda.synchronize()
     for k, p in model.named_parameters():
@@ -151,7 +151,7 @@ def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, pre
         assert (p.grad - want).abs().max() <= 1e-5 * want.abs().max() + 1e-9, k
     # backward is over: the leases are released although `la` / `lb` (and their graphs) are still bound -- the usual training
     # loop keeps the previous iteration's loss alive while the next forward runs and must not ping-pong between two workspaces
-    ws_pool = model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device))]
+    ws_pool = model.engine()._ws[(x1.shape[0], x1.shape[2], x1.shape[3], str(x1.device), 0)]
     assert not any(w.leased for w in ws_pool)
     lc = _tversky_torch(model(x1, x2), lbl)
     assert len(ws_pool) == 2 and ws_pool[0].leased
