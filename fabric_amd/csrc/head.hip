@@ -488,23 +488,38 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
     int c_tp = 0, c_fp = 0, c_fn = 0, c_ok = 0;
     const int rows = B * H, r_end = min(rows, (int)(blockIdx.y + 1) * rows_per_block);
     if (x < W)
-        for (int r = blockIdx.y * rows_per_block + rl; r < r_end; r += RL) {
-            const int b = r / H, y = r % H;
-            const size_t q = (size_t)y * W + x;
-            float l[NC]; float m = -INFINITY; int am = 0;
+        // four rows of a lane are requested before the first is used (a lane walks 16 rows at B = 64: one dependent HBM round trip
+        // per row made this pass 17.6 us for 9 MB); the rows are still ACCUMULATED one after the other, in the same order
+        for (int r0 = blockIdx.y * rows_per_block + rl; r0 < r_end; r0 += 4 * RL) {
+            float lv[4][NC]; int tv[4];
 #pragma unroll
-            for (int k = 0; k < NC; k++) { l[k] = k < ncls ? logits[((size_t)b * ncls + k) * hw + q] : -INFINITY; if (l[k] > m) { m = l[k]; am = k; } }
-            float den = 0.f;
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + u * RL;
+                const int rr = r < r_end ? r : r0;
+                const int b = rr / H, y = rr % H;
+                const size_t q = (size_t)y * W + x;
 #pragma unroll
-            for (int k = 0; k < NC; k++) { l[k] = k < ncls ? expf(l[k] - m) : 0.f; den += l[k]; }
-            const int t = labels[(size_t)b * hw + q];
-            const float inv = 1.f / den;
-#pragma unroll
-            for (int k = 0; k < NC; k++) {
-                const float p = l[k] * inv;
-                if (t == k) { tp[k] += p; fn[k] += 1.f - p; } else fp[k] += p;
+                for (int k = 0; k < NC; k++) lv[u][k] = k < ncls ? logits[((size_t)b * ncls + k) * hw + q] : -INFINITY;
+                tv[u] = labels[(size_t)b * hw + q];
             }
-            c_tp += (am == 1 && t == 1); c_fp += (am == 1 && t != 1); c_fn += (am != 1 && t == 1); c_ok += (am == t);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (r0 + u * RL >= r_end) break;
+                float l[NC]; float m = -INFINITY; int am = 0;
+#pragma unroll
+                for (int k = 0; k < NC; k++) { l[k] = lv[u][k]; if (l[k] > m) { m = l[k]; am = k; } }
+                float den = 0.f;
+#pragma unroll
+                for (int k = 0; k < NC; k++) { l[k] = k < ncls ? expf(l[k] - m) : 0.f; den += l[k]; }
+                const int t = tv[u];
+                const float inv = 1.f / den;
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    const float p = l[k] * inv;
+                    if (t == k) { tp[k] += p; fn[k] += 1.f - p; } else fp[k] += p;
+                }
+                c_tp += (am == 1 && t == 1); c_fp += (am == 1 && t != 1); c_fn += (am != 1 && t == 1); c_ok += (am == t);
+            }
         }
 #pragma unroll
     for (int k = 0; k < NC; k++) {
