@@ -17,6 +17,24 @@ __device__ __forceinline__ float act1(float z, float sc, float sh) {
     return to_f(from_f<T>(fmaxf(fmaf(z, sc, sh), 0.f)));
 }
 
+// a lane's channel unit of E elements: 16 bytes (Unit<T>) or, for bf16 kernels that are short of registers, 8 bytes
+template <typename T, int E> struct UnitE;
+template <> struct UnitE<bf16s, 8> : Unit<bf16s> { using V = uint4; __device__ __forceinline__ static V zero() { return make_uint4(0, 0, 0, 0); } };
+template <> struct UnitE<float, 4> : Unit<float> { using V = uint4; __device__ __forceinline__ static V zero() { return make_uint4(0, 0, 0, 0); } };
+template <> struct UnitE<bf16s, 4> {
+    using V = uint2;
+    __device__ __forceinline__ static V zero() { return make_uint2(0, 0); }
+    __device__ __forceinline__ static void unpack(const uint2& u, float* f) {
+        f[0] = bf2f(u.x & 0xffffu); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffffu); f[3] = bf2f(u.y >> 16);
+    }
+    __device__ __forceinline__ static uint2 pack(const float* f) { return make_uint2(f2bf2(f[0], f[1]), f2bf2(f[2], f[3])); }
+};
+template <int E>
+__device__ __forceinline__ void load_consts_n(const float* __restrict__ p, float (&o)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; i++) o[i] = p[i];
+}
+
 constexpr int ITERS = 8;        // pixels per thread
 
 // ============================================================ bnrelu + MaxPool2d(2)
@@ -575,41 +593,44 @@ extern "C" int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* d
 // sum g*z with g = dA * [relu(bn(z)) > 0], on the STORED, rounded dA), so no separate reduction pass reads dA and z.
 // The two-pass variant that never writes dA (sums pass + fused apply pass, 22 % fewer bytes) measured +1.9 % step time in
 // round 2 -- its argmax / product work runs twice -- and lives in tools/experimental/enc_skip_two_pass.hip.inc.
-template <typename T>
-__global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
+#ifndef ENC_SKIP_BLOCKS
+#define ENC_SKIP_BLOCKS 1
+#endif
+template <typename T, int EPU>
+__global__ __launch_bounds__(256, ENC_SKIP_BLOCKS) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
                                     const T* __restrict__ dP, T* __restrict__ dA, float* __restrict__ bs_partial,
-                                    int B, int H, int W, int C, int ncell) {
-    constexpr int EPU = ET<T>::EPU;
+                                    int B, int H, int W, int C, int ncell, int IT) {
+    using U = UnitE<T, EPU>;
+    using V = typename U::V;
     extern __shared__ float sred[];                            // [256][EPU][4] when bs_partial
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
     float sc0[EPU], sh0[EPU], sc1[EPU], sh1[EPU];
-    load_consts<T>(bn_row(bn, 0, 2, C) + c, sc0); load_consts<T>(bn_row(bn, 0, 3, C) + c, sh0);
-    load_consts<T>(bn_row(bn, 1, 2, C) + c, sc1); load_consts<T>(bn_row(bn, 1, 3, C) + c, sh1);
+    load_consts_n<EPU>(bn_row(bn, 0, 2, C) + c, sc0); load_consts_n<EPU>(bn_row(bn, 0, 3, C) + c, sh0);
+    load_consts_n<EPU>(bn_row(bn, 1, 2, C) + c, sc1); load_consts_n<EPU>(bn_row(bn, 1, 3, C) + c, sh1);
     float t00[EPU], t01[EPU], t10[EPU], t11[EPU];              // [date][sum g | sum g*z]
 #pragma unroll
     for (int i = 0; i < EPU; i++) { t00[i] = 0.f; t01[i] = 0.f; t10[i] = 0.f; t11[i] = 0.f; }
     const bool bs = bs_partial != nullptr;
-    constexpr int IT = 4;
     const int q_end = min(ncell, (int)(blockIdx.x + 1) * rows * IT);
     for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
         const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
         const bool pooled = dP != nullptr && yc < Ho && xc < Wo;   // floor-mode pooling leaves a trailing odd row/col unpooled
         // every input of the cell is requested up front (z of both dates: 8 units, dF: 4, dP: 2) and z is kept in registers for
         // both passes: the first version re-loaded z in pass 2 behind the wait of pass 1 -- two dependent round trips per cell
-        uint4 zq0[4], zq1[4], dfq[4], gq0 = make_uint4(0, 0, 0, 0), gq1 = make_uint4(0, 0, 0, 0);
+        V zq0[4], zq1[4], dfq[4], gq0 = U::zero(), gq1 = U::zero();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
             const bool in = y < H && x < W;
             const size_t p0 = ((size_t)(b * H + (in ? y : 2 * yc)) * W + (in ? x : 2 * xc)), p1 = p0 + (size_t)B * H * W;
-            zq0[k] = *reinterpret_cast<const uint4*>(z + p0 * C + c);
-            zq1[k] = *reinterpret_cast<const uint4*>(z + p1 * C + c);
-            dfq[k] = *reinterpret_cast<const uint4*>(dF + p0 * ldF + c);
+            zq0[k] = *reinterpret_cast<const V*>(z + p0 * C + c);
+            zq1[k] = *reinterpret_cast<const V*>(z + p1 * C + c);
+            dfq[k] = *reinterpret_cast<const V*>(dF + p0 * ldF + c);
         }
         if (pooled) {
-            gq0 = *reinterpret_cast<const uint4*>(dP + ((size_t)(b * Ho + yc) * Wo + xc) * C + c);
-            gq1 = *reinterpret_cast<const uint4*>(dP + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c);
+            gq0 = *reinterpret_cast<const V*>(dP + ((size_t)(b * Ho + yc) * Wo + xc) * C + c);
+            gq1 = *reinterpret_cast<const V*>(dP + ((size_t)((B + b) * Ho + yc) * Wo + xc) * C + c);
         }
         // ---- pass 1: position of the FIRST maximum of each window (strict >, like ATen's max_pool2d)
         unsigned idx0 = 0, idx1 = 0;                               // 2 bits per channel
@@ -620,8 +641,8 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 float f0[EPU], f1[EPU];                                      // pooled windows are complete
-                Unit<T>::unpack(zq0[k], f0);
-                Unit<T>::unpack(zq1[k], f1);
+                U::unpack(zq0[k], f0);
+                U::unpack(zq1[k], f1);
 #pragma unroll
                 for (int i = 0; i < EPU; i++) {
                     const float a0 = act1<T>(f0[i], sc0[i], sh0[i]), a1 = act1<T>(f1[i], sc1[i], sh1[i]);
@@ -633,7 +654,7 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
         float g0[EPU], g1[EPU];
 #pragma unroll
         for (int i = 0; i < EPU; i++) { g0[i] = 0.f; g1[i] = 0.f; }
-        if (pooled) { Unit<T>::unpack(gq0, g0); Unit<T>::unpack(gq1, g1); }
+        if (pooled) { U::unpack(gq0, g0); U::unpack(gq1, g1); }
         // ---- pass 2: gradients (and statistics)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -641,9 +662,9 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
             if (y < H && x < W) {
                 float f0[EPU], f1[EPU], df[EPU], o0[EPU], o1[EPU];
                 const size_t p0 = ((size_t)(b * H + y) * W + x), p1 = ((size_t)((B + b) * H + y) * W + x);
-                Unit<T>::unpack(zq0[k], f0);
-                Unit<T>::unpack(zq1[k], f1);
-                Unit<T>::unpack(dfq[k], df);
+                U::unpack(zq0[k], f0);
+                U::unpack(zq1[k], f1);
+                U::unpack(dfq[k], df);
 #pragma unroll
                 for (int i = 0; i < EPU; i++) {
                     const float a0 = act1<T>(f0[i], sc0[i], sh0[i]), a1 = act1<T>(f1[i], sc1[i], sh1[i]);
@@ -652,11 +673,11 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
                     if (pooled && ((idx0 >> (2 * i)) & 3u) == (unsigned)k) o0[i] += g0[i];
                     if (pooled && ((idx1 >> (2 * i)) & 3u) == (unsigned)k) o1[i] += g1[i];
                 }
-                const uint4 u0 = Unit<T>::pack(o0), u1 = Unit<T>::pack(o1);
-                *reinterpret_cast<uint4*>(dA + p0 * C + c) = u0;
-                *reinterpret_cast<uint4*>(dA + p1 * C + c) = u1;
+                const V u0 = U::pack(o0), u1 = U::pack(o1);
+                *reinterpret_cast<V*>(dA + p0 * C + c) = u0;
+                *reinterpret_cast<V*>(dA + p1 * C + c) = u1;
                 if (bs) {
-                    Unit<T>::unpack(u0, o0); Unit<T>::unpack(u1, o1);       // what BatchNorm backward will read back
+                    U::unpack(u0, o0); U::unpack(u1, o1);       // what BatchNorm backward will read back
 #pragma unroll
                     for (int i = 0; i < EPU; i++) {
                         const float m0 = fmaf(f0[i], sc0[i], sh0[i]) > 0.f ? o0[i] : 0.f;
@@ -685,9 +706,21 @@ __global__ __launch_bounds__(256) void enc_skip_bwd_kernel(const T* __restrict__
     }
 }
 
+// elements per lane: bf16 lanes own 8 BYTES (four channels) -- with 16-byte units the kernel needs 196 registers (two waves per SIMD) and
+// streams at 4.0-4.6 TB/s where its float32 instantiation (128 registers) reaches 5.4
+static inline int enc_skip_epu(int dtype) { return 4; (void)dtype; }
+// cells per lane: four where that still leaves >= 512 blocks, else two, else one (the 16x16 and 8x8 levels ran on 256 and 64 blocks:
+// 2.9 and 1.0 TB/s)
+static inline int enc_skip_bwd_it(int dtype, int B, int H, int W, int C) {
+    const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
+    const int rows = 256 / (C / enc_skip_epu(dtype));
+    for (int it = 4; it > 1; it >>= 1)
+        if (ncell / (rows * it) >= 512) return it;
+    return 1;
+}
 static inline int enc_skip_bwd_blocks(int dtype, int B, int H, int W, int C) {
     const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
-    const int per = 256 / (C / (dtype == BDN_BF16 ? 8 : 4)) * 4;
+    const int per = 256 / (C / enc_skip_epu(dtype)) * enc_skip_bwd_it(dtype, B, H, W, C);
     return (ncell + per - 1) / per;
 }
 
@@ -705,11 +738,11 @@ extern "C" int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* 
     const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
     const int grid = enc_skip_bwd_blocks(dtype, B, H, W, C);
     if (dtype == BDN_BF16)
-        hipLaunchKernelGGL(enc_skip_bwd_kernel<bf16s>, dim3(grid), dim3(256), bs_partial ? 256 * 8 * 4 * sizeof(float) : 0, st,
-                           (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, bs_partial, B, H, W, C, ncell);
+        hipLaunchKernelGGL((enc_skip_bwd_kernel<bf16s, 4>), dim3(grid), dim3(256), bs_partial ? 256 * 4 * 4 * sizeof(float) : 0, st,
+                           (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, bs_partial, B, H, W, C, ncell, enc_skip_bwd_it(dtype, B, H, W, C));
     else if (dtype == BDN_F32)
-        hipLaunchKernelGGL(enc_skip_bwd_kernel<float>, dim3(grid), dim3(256), bs_partial ? 256 * 4 * 4 * sizeof(float) : 0, st,
-                           (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, bs_partial, B, H, W, C, ncell);
+        hipLaunchKernelGGL((enc_skip_bwd_kernel<float, 4>), dim3(grid), dim3(256), bs_partial ? 256 * 4 * 4 * sizeof(float) : 0, st,
+                           (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, bs_partial, B, H, W, C, ncell, enc_skip_bwd_it(dtype, B, H, W, C));
     else BDN_FAIL(BDN_E_ARG, "enc_skip_bwd: bad dtype");
     BDN_CHECK_LAUNCH("enc_skip_bwd");
     return BDN_OK;

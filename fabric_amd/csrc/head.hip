@@ -207,26 +207,37 @@ __global__ void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict
 #pragma unroll
         for (int i = 0; i < EPU; i++) wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f;
     const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_ITERS);
-    for (int p0 = blockIdx.x * rows * OUTC_ITERS; p0 < p_end; p0 += rows) {       // block-uniform trip count
-        const int p = p0 + row;
-        float f[EPU], acc[NC];
+    // four pixels of a lane are requested before the first is used: with one 16-byte load in flight per lane the pass ran at 3.6 TB/s
+    for (int p0 = blockIdx.x * rows * OUTC_ITERS; p0 < p_end; p0 += 4 * rows) {   // block-uniform trip count
+        uint4 u[4];
 #pragma unroll
-        for (int k = 0; k < NC; k++) acc[k] = 0.f;
-        if (p < p_end) {
-            Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), f);
-#pragma unroll
-            for (int i = 0; i < EPU; i++) {
-                const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
-#pragma unroll
-                for (int k = 0; k < NC; k++) acc[k] = fmaf(a, wk[k][i], acc[k]);
-            }
+        for (int j = 0; j < 4; j++) {
+            const int p = p0 + j * rows + row;
+            u[j] = *reinterpret_cast<const uint4*>(z + (size_t)(p < p_end ? p : p0) * C + c);
         }
 #pragma unroll
-        for (int k = 0; k < NC; k++)
-            for (int off = CU >> 1; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
-        if (cu == 0 && p < p_end) {
-            const int b = p / hw, q = p % hw;
-            for (int k = 0; k < ncls; k++) logits[((size_t)b * ncls + k) * hw + q] = acc[k] + bias[k];
+        for (int j = 0; j < 4; j++) {
+            const int p = p0 + j * rows + row;
+            if (p0 + j * rows >= p_end) break;                                    // block-uniform
+            float f[EPU], acc[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) acc[k] = 0.f;
+            if (p < p_end) {
+                Unit<T>::unpack(u[j], f);
+#pragma unroll
+                for (int i = 0; i < EPU; i++) {
+                    const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
+#pragma unroll
+                    for (int k = 0; k < NC; k++) acc[k] = fmaf(a, wk[k][i], acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                for (int off = CU >> 1; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+            if (cu == 0 && p < p_end) {
+                const int b = p / hw, q = p % hw;
+                for (int k = 0; k < ncls; k++) logits[((size_t)b * ncls + k) * hw + q] = acc[k] + bias[k];
+            }
         }
     }
 }
@@ -274,32 +285,46 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
     }
     __syncthreads();
     const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_BWD_ITERS);
-    for (int p = blockIdx.x * rows * OUTC_BWD_ITERS + row; p < p_end; p += rows) {
-        const int b = p / hw, q = p % hw;
-        float g[NC], f[EPU], o[EPU];
+    for (int pb = blockIdx.x * rows * OUTC_BWD_ITERS + row; pb < p_end; pb += 4 * rows) {
+        // four pixels of a lane are requested before the first is used; they are still accumulated one after the other, in order
+        uint4 zu[4]; float gv[4][NC];
 #pragma unroll
-        for (int k = 0; k < NC; k++) g[k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
-        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), f);
+        for (int j = 0; j < 4; j++) {
+            const int pj = pb + j * rows < p_end ? pb + j * rows : pb;
+            const int b = pj / hw, q = pj % hw;
 #pragma unroll
-        for (int i = 0; i < EPU; i++) {
-            const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < NC; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
-            o[i] = s;
+            for (int k = 0; k < NC; k++) gv[j][k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
+            zu[j] = *reinterpret_cast<const uint4*>(z + (size_t)pj * C + c);
         }
-        if (cu == 0) {
 #pragma unroll
-            for (int k = 0; k < NC; k++) accb[k] += g[k];
-        }
-        const uint4 uo = Unit<T>::pack(o);
-        if (dA) *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
-        if (bs) {                                             // BatchNorm-backward partial sums of this layer on the stored gradient
-            Unit<T>::unpack(uo, o);
+        for (int j = 0; j < 4; j++) {
+            const int p = pb + j * rows;
+            if (p >= p_end) break;
+            float g[NC], f[EPU], o[EPU];
+#pragma unroll
+            for (int k = 0; k < NC; k++) g[k] = gv[j][k];
+            Unit<T>::unpack(zu[j], f);
 #pragma unroll
             for (int i = 0; i < EPU; i++) {
-                const float gm = fmaf(f[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
-                t0[i] += gm; t1[i] = fmaf(gm, f[i], t1[i]);
+                const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < NC; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
+                o[i] = s;
+            }
+            if (cu == 0) {
+#pragma unroll
+                for (int k = 0; k < NC; k++) accb[k] += g[k];
+            }
+            const uint4 uo = Unit<T>::pack(o);
+            if (dA) *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
+            if (bs) {                                             // BatchNorm-backward partial sums of this layer on the stored gradient
+                Unit<T>::unpack(uo, o);
+#pragma unroll
+                for (int i = 0; i < EPU; i++) {
+                    const float gm = fmaf(f[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
+                    t0[i] += gm; t1[i] = fmaf(gm, f[i], t1[i]);
+                }
             }
         }
     }
@@ -413,38 +438,50 @@ __global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __r
     for (int k = 0; k < NC; k++)
 #pragma unroll
         for (int i = 0; i < EPU; i++) wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f;
-    for (int p = p_begin + row; p < p_end; p += rows) {
-        const int g = p / pix_per_group;
-        if (g != gcur) {                                   // (blocks never straddle groups in practice; correct if they do)
-            gcur = g;
+    for (int pb = p_begin + row; pb < p_end; pb += 4 * rows) {
+        // four pixels of a lane are requested before the first is used
+        uint4 zu[4]; float gv[4][NC];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int pj = pb + j * rows < p_end ? pb + j * rows : pb;
+            const int b = pj / hw, q = pj % hw;
+#pragma unroll
+            for (int k = 0; k < NC; k++) gv[j][k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
+            zu[j] = *reinterpret_cast<const uint4*>(z + (size_t)pj * C + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = pb + j * rows;
+            if (p >= p_end) break;
+            const int g = p / pix_per_group;
+            if (g != gcur) {                                   // (blocks never straddle groups in practice; correct if they do)
+                gcur = g;
+#pragma unroll
+                for (int i = 0; i < EPU; i++) {
+                    mean[i] = bn_row(bn, g, 0, C)[c + i]; inv[i] = bn_row(bn, g, 1, C)[c + i];
+                    sc[i] = bn_row(bn, g, 2, C)[c + i]; sh[i] = bn_row(bn, g, 3, C)[c + i];
+                    k0[i] = sums[((size_t)g * 2 + 0) * C + c + i] * invM;
+                    k1[i] = sums[((size_t)g * 2 + 1) * C + c + i] * invM;
+                }
+            }
+            float fz[EPU], o[EPU];
+            Unit<T>::unpack(zu[j], fz);
 #pragma unroll
             for (int i = 0; i < EPU; i++) {
-                mean[i] = bn_row(bn, g, 0, C)[c + i]; inv[i] = bn_row(bn, g, 1, C)[c + i];
-                sc[i] = bn_row(bn, g, 2, C)[c + i]; sh[i] = bn_row(bn, g, 3, C)[c + i];
-                k0[i] = sums[((size_t)g * 2 + 0) * C + c + i] * invM;
-                k1[i] = sums[((size_t)g * 2 + 1) * C + c + i] * invM;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < NC; k++) if (k < ncls) s = fmaf(gv[j][k], wk[k][i], s);
+                o[i] = s;
             }
+            Unit<T>::unpack(Unit<T>::pack(o), o);              // the gradient as outc_bwd would have stored it
+#pragma unroll
+            for (int i = 0; i < EPU; i++) {
+                const float gm = fmaf(fz[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
+                const float xhat = (fz[i] - mean[i]) * inv[i];
+                o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
+            }
+            *reinterpret_cast<uint4*>(dz + (size_t)p * C + c) = Unit<T>::pack(o);
         }
-        const int b = p / hw, q = p % hw;
-        float gl[NC], fz[EPU], o[EPU];
-#pragma unroll
-        for (int k = 0; k < NC; k++) gl[k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
-        Unit<T>::unpack(*reinterpret_cast<const uint4*>(z + (size_t)p * C + c), fz);
-#pragma unroll
-        for (int i = 0; i < EPU; i++) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < NC; k++) if (k < ncls) s = fmaf(gl[k], wk[k][i], s);
-            o[i] = s;
-        }
-        Unit<T>::unpack(Unit<T>::pack(o), o);              // the gradient as outc_bwd would have stored it
-#pragma unroll
-        for (int i = 0; i < EPU; i++) {
-            const float gm = fmaf(fz[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
-            const float xhat = (fz[i] - mean[i]) * inv[i];
-            o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
-        }
-        *reinterpret_cast<uint4*>(dz + (size_t)p * C + c) = Unit<T>::pack(o);
     }
 }
 
