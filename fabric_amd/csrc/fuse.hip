@@ -156,7 +156,7 @@ extern "C" int bdn_fuse_product(int dtype, const void* z, const float* bn, void*
 // iteration = one 2x2 window x EPU channels x both dates, so z is read from HBM once instead of twice.
 template <typename T>
 __global__ void product_pool_kernel(const T* __restrict__ z, const float* __restrict__ bn, T* __restrict__ f, T* __restrict__ pool,
-                                    int B, int H, int W, int C, int ncell, SplitOut sf, SplitOut sp) {
+                                    int B, int H, int W, int C, int ncell, SplitOut sf, SplitOut sp, FastDiv dWc, FastDiv dHc) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
@@ -166,7 +166,7 @@ __global__ void product_pool_kernel(const T* __restrict__ z, const float* __rest
     constexpr int IT = 4;
     const int q_end = min(ncell, (int)(blockIdx.x + 1) * rows * IT);
     for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
-        const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
+        int xc, t, yc, b; dWc.divmod(q, t, xc); dHc.divmod(t, b, yc);
         float m0[EPU], m1[EPU];
 #pragma unroll
         for (int i = 0; i < EPU; i++) { m0[i] = 0.f; m1[i] = 0.f; }     // activations are >= 0
@@ -201,9 +201,9 @@ static int product_pool_impl(int dtype, const void* z, const float* bn, void* f,
     hipStream_t st = (hipStream_t)stream;
     const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
     if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
-        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell, sf, sp); }
+        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell, sf, sp, FastDiv((W + 1) / 2), FastDiv((H + 1) / 2)); }
     else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
-        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell, sf, sp); }
+        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell, sf, sp, FastDiv((W + 1) / 2), FastDiv((H + 1) / 2)); }
     else BDN_FAIL(BDN_E_ARG, "product_pool: bad dtype");
     BDN_CHECK_LAUNCH("product_pool");
     return BDN_OK;
@@ -599,7 +599,7 @@ extern "C" int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* d
 template <typename T, int EPU>
 __global__ __launch_bounds__(256, ENC_SKIP_BLOCKS) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
                                     const T* __restrict__ dP, T* __restrict__ dA, float* __restrict__ bs_partial,
-                                    int B, int H, int W, int C, int ncell, int IT) {
+                                    int B, int H, int W, int C, int ncell, int IT, FastDiv dWc, FastDiv dHc) {
     using U = UnitE<T, EPU>;
     using V = typename U::V;
     extern __shared__ float sred[];                            // [256][EPU][4] when bs_partial
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, ENC_SKIP_BLOCKS) void enc_skip_bwd_kernel(cons
     const bool bs = bs_partial != nullptr;
     const int q_end = min(ncell, (int)(blockIdx.x + 1) * rows * IT);
     for (int q = blockIdx.x * rows * IT + row; q < q_end; q += rows) {
-        const int xc = q % Wc, t = q / Wc, yc = t % Hc, b = t / Hc;
+        int xc, t, yc, b; dWc.divmod(q, t, xc); dHc.divmod(t, b, yc);
         const bool pooled = dP != nullptr && yc < Ho && xc < Wo;   // floor-mode pooling leaves a trailing odd row/col unpooled
         // every input of the cell is requested up front (z of both dates: 8 units, dF: 4, dP: 2) and z is kept in registers for
         // both passes: the first version re-loaded z in pass 2 behind the wait of pass 1 -- two dependent round trips per cell
@@ -739,10 +739,10 @@ extern "C" int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* 
     const int grid = enc_skip_bwd_blocks(dtype, B, H, W, C);
     if (dtype == BDN_BF16)
         hipLaunchKernelGGL((enc_skip_bwd_kernel<bf16s, 4>), dim3(grid), dim3(256), bs_partial ? 256 * 4 * 4 * sizeof(float) : 0, st,
-                           (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, bs_partial, B, H, W, C, ncell, enc_skip_bwd_it(dtype, B, H, W, C));
+                           (const bf16s*)dF, ldF, (const bf16s*)z, bn, (const bf16s*)dP, (bf16s*)dA, bs_partial, B, H, W, C, ncell, enc_skip_bwd_it(dtype, B, H, W, C), FastDiv((W + 1) / 2), FastDiv((H + 1) / 2));
     else if (dtype == BDN_F32)
         hipLaunchKernelGGL((enc_skip_bwd_kernel<float, 4>), dim3(grid), dim3(256), bs_partial ? 256 * 4 * 4 * sizeof(float) : 0, st,
-                           (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, bs_partial, B, H, W, C, ncell, enc_skip_bwd_it(dtype, B, H, W, C));
+                           (const float*)dF, ldF, (const float*)z, bn, (const float*)dP, (float*)dA, bs_partial, B, H, W, C, ncell, enc_skip_bwd_it(dtype, B, H, W, C), FastDiv((W + 1) / 2), FastDiv((H + 1) / 2));
     else BDN_FAIL(BDN_E_ARG, "enc_skip_bwd: bad dtype");
     BDN_CHECK_LAUNCH("enc_skip_bwd");
     return BDN_OK;

@@ -11,15 +11,15 @@ static inline unsigned grid_for(size_t n, int block = 256) { return (unsigned)((
 // (the first version wrote Cpad scalars per thread: 100 us for 176 MB).
 template <typename T>
 __global__ void pack_input_kernel(const float* __restrict__ x1, const float* __restrict__ x2, T* __restrict__ out,
-                                  int B, int C, int H, int W, int Cpad) {
+                                  int B, int C, int H, int W, int Cpad, FastDiv dhw, FastDiv dupp) {
     constexpr int EPU = ET<T>::EPU;
     const int upp = Cpad / EPU;
     const size_t hw = (size_t)H * W, total = (size_t)2 * B * hw * upp;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     // the unit index is the slow coordinate inside an image so that a wave reads 64 consecutive pixels of one plane set
-    const size_t p = i % hw; size_t t = i / hw;
-    const int u = t % upp; const int n = t / upp;
+    int ti, pi, n, u; dhw.divmod((int)i, ti, pi); dupp.divmod(ti, n, u);        // (total < 2^31: the entry point keeps the tensor below 4 GB)
+    const size_t p = pi;
     const float* src = (n < B ? x1 + (size_t)n * C * hw : x2 + (size_t)(n - B) * C * hw) + p;
     float f[EPU];
 #pragma unroll
@@ -33,8 +33,9 @@ extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, v
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || Cpad % 16) BDN_FAIL(BDN_E_SHAPE, "pack_input: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)2 * B * H * W;
-    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16s>, dim3(grid_for(npix * (Cpad / 8))), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad);
-    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(npix * (Cpad / 4))), dim3(256), 0, st, x_d1, x_d2, (float*)out, B, C, H, W, Cpad);
+    if (npix * (Cpad / 4) >= ((size_t)1 << 31)) BDN_FAIL(BDN_E_SHAPE, "pack_input: 2*B*H*W*Cpad/4 = %zu reaches 2^31; split the batch", npix * (Cpad / 4));
+    if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16s>, dim3(grid_for(npix * (Cpad / 8))), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad, FastDiv(H * W), FastDiv(Cpad / 8));
+    else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(npix * (Cpad / 4))), dim3(256), 0, st, x_d1, x_d2, (float*)out, B, C, H, W, Cpad, FastDiv(H * W), FastDiv(Cpad / 4));
     else BDN_FAIL(BDN_E_ARG, "pack_input: bad dtype");
     BDN_CHECK_LAUNCH("pack_input");
     return BDN_OK;
@@ -196,7 +197,7 @@ constexpr int OUTC_BWD_ITERS = 32;  // ... and backward: every block ends with 1
 // fully coalesced), partial dot products are combined with xor-shuffles inside the CU-lane group.
 template <typename T, int NC>
 __global__ void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ w,
-                                const float* __restrict__ bias, float* __restrict__ logits, int npix, int hw, int C, int ncls) {
+                                const float* __restrict__ bias, float* __restrict__ logits, int npix, int hw, int C, int ncls, FastDiv dhw) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     float sc[EPU], sh[EPU], wk[NC][EPU];
@@ -235,7 +236,7 @@ __global__ void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict
             for (int k = 0; k < NC; k++)
                 for (int off = CU >> 1; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
             if (cu == 0 && p < p_end) {
-                const int b = p / hw, q = p % hw;
+                int b, q; dhw.divmod(p, b, q);
                 for (int k = 0; k < ncls; k++) logits[((size_t)b * ncls + k) * hw + q] = acc[k] + bias[k];
             }
         }
@@ -249,12 +250,12 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
     hipStream_t st = (hipStream_t)stream; const int npix = B * H * W, hw = H * W;
     if (dtype == BDN_BF16) {
         const int per = 256 / (C / 8) * OUTC_ITERS; const unsigned grid = (npix + per - 1) / per;
-        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<bf16s, 2>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls);
-        else hipLaunchKernelGGL((outc_fwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls);
+        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<bf16s, 2>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
+        else hipLaunchKernelGGL((outc_fwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
     } else if (dtype == BDN_F32) {
         const int per = 256 / (C / 4) * OUTC_ITERS; const unsigned grid = (npix + per - 1) / per;
-        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls);
-        else hipLaunchKernelGGL((outc_fwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls);
+        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
+        else hipLaunchKernelGGL((outc_fwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
     }
     else BDN_FAIL(BDN_E_ARG, "outc_fwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_fwd");
@@ -268,7 +269,7 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
                                 const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ wpart,
-                                float* __restrict__ bs_partial, int npix, int hw, int C, int ncls) {
+                                float* __restrict__ bs_partial, int npix, int hw, int C, int ncls, FastDiv dhw) {
     constexpr int EPU = ET<T>::EPU;
     extern __shared__ float sm[];                             // [ncls][C+1] block sums + [256][EPU][2] reduction scratch
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int pj = pb + j * rows < p_end ? pb + j * rows : pb;
-            const int b = pj / hw, q = pj % hw;
+            int b, q; dhw.divmod(pj, b, q);
 #pragma unroll
             for (int k = 0; k < NC; k++) gv[j][k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
             zu[j] = *reinterpret_cast<const uint4*>(z + (size_t)pj * C + c);
@@ -407,11 +408,11 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
     const unsigned grid = bdn_outc_bwd_rows(dtype, B, H, W, C);
     const size_t smem = sizeof(float) * (ncls * (C + 1) + 256 * (dtype == BDN_BF16 ? 8 : 4) * 2);
     if (dtype == BDN_BF16) {
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls);
-        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls);
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
+        else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
     } else if (dtype == BDN_F32) {
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls);
-        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls);
+        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
+        else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
     } else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
     hipLaunchKernelGGL(outc_dw_reduce_kernel, dim3(ncls * (C + 1)), dim3(256), 0, st, ws, (int)grid, C, ncls, dw, db);
@@ -426,7 +427,7 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __restrict__ dl, const float* __restrict__ w,
                                 const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ sums,
-                                T* __restrict__ dz, int npix, int hw, int pix_per_group, int pix_per_block, int C, int ncls) {
+                                T* __restrict__ dz, int npix, int hw, int pix_per_group, int pix_per_block, int C, int ncls, FastDiv dhw, FastDiv dppg) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int p_begin = blockIdx.x * pix_per_block, p_end = min(npix, p_begin + pix_per_block);
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int pj = pb + j * rows < p_end ? pb + j * rows : pb;
-            const int b = pj / hw, q = pj % hw;
+            int b, q; dhw.divmod(pj, b, q);
 #pragma unroll
             for (int k = 0; k < NC; k++) gv[j][k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
             zu[j] = *reinterpret_cast<const uint4*>(z + (size_t)pj * C + c);
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __r
         for (int j = 0; j < 4; j++) {
             const int p = pb + j * rows;
             if (p >= p_end) break;
-            const int g = p / pix_per_group;
+            const int g = dppg.div(p);
             if (g != gcur) {                                   // (blocks never straddle groups in practice; correct if they do)
                 gcur = g;
 #pragma unroll
@@ -495,7 +496,7 @@ extern "C" int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const floa
     int ppb = (npix + 2047) / 2048; if (ppb < 2 * rows) ppb = 2 * rows; ppb = (ppb + rows - 1) / rows * rows;
     const unsigned grid = (npix + ppb - 1) / ppb;
 #define OUTC_APPLY(T_, NC_) hipLaunchKernelGGL((outc_bn_bwd_apply_kernel<T_, NC_>), dim3(grid), dim3(256), 0, st, dlogits, w, (const T_*)z, bn, sums, \
-                                               (T_*)dz, npix, H * W, imgs_per_group * H * W, ppb, C, ncls)
+                                               (T_*)dz, npix, H * W, imgs_per_group * H * W, ppb, C, ncls, FastDiv(H * W), FastDiv(imgs_per_group * H * W))
     if (dtype == BDN_BF16) { if (ncls <= 2) OUTC_APPLY(bf16s, 2); else OUTC_APPLY(bf16s, OUTC_MAXCLS); }
     else if (dtype == BDN_F32) { if (ncls <= 2) OUTC_APPLY(float, 2); else OUTC_APPLY(float, OUTC_MAXCLS); }
     else BDN_FAIL(BDN_E_ARG, "outc_bn_bwd_apply: bad dtype");
@@ -511,7 +512,7 @@ extern "C" int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const floa
 template <int NC>
 __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
                                     float* __restrict__ part, int32_t* __restrict__ pcounts, int B, int ncls, int H, int W,
-                                    int rows_per_block, int We) {
+                                    int rows_per_block, int We, FastDiv dH) {
     // block = 256 threads = RL row lanes x CW columns (CW = min(W rounded up to a power of two, 256));
     // grid.x = column blocks, grid.y = row blocks
     extern __shared__ float sm[];                         // [RL][3*NC][CW]
@@ -533,7 +534,7 @@ __global__ void tversky_sums_kernel(const float* __restrict__ logits, const uint
             for (int u = 0; u < 4; u++) {
                 const int r = r0 + u * RL;
                 const int rr = r < r_end ? r : r0;
-                const int b = rr / H, y = rr % H;
+                int b, y; dH.divmod(rr, b, y);
                 const size_t q = (size_t)y * W + x;
 #pragma unroll
                 for (int k = 0; k < NC; k++) lv[u][k] = k < ncls ? logits[((size_t)b * ncls + k) * hw + q] : -INFINITY;
@@ -661,11 +662,12 @@ __global__ __launch_bounds__(1024) void tversky_finish_kernel(float* __restrict_
 
 __global__ void tversky_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
                                    const float* __restrict__ coef, float alpha, float beta, float* __restrict__ dlogits,
-                                   int B, int ncls, int H, int Wimg, int W) {
+                                   int B, int ncls, int H, int Wimg, int W, FastDiv dhw, FastDiv dWimg) {
     const size_t hw = (size_t)H * Wimg, npix = (size_t)B * hw;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    const size_t b = p / hw, q = p % hw; const int x = W == 1 ? 0 : (int)(q % Wimg);
+    int bi, qi, yi, xi; dhw.divmod((int)p, bi, qi); dWimg.divmod(qi, yi, xi);      // (the entry point keeps B*H*W below 2^31)
+    const size_t b = bi, q = qi; const int x = W == 1 ? 0 : xi;
     const int n = ncls * W;
     float l[OUTC_MAXCLS], dp[OUTC_MAXCLS]; float m = -INFINITY;
 #pragma unroll
@@ -713,20 +715,20 @@ extern "C" int bdn_overlap_loss(const float* logits, const uint8_t* labels, floa
                                 int B, int ncls, int H, int W, void* stream) {
     if (!logits || !labels || !ws || !loss) BDN_FAIL(BDN_E_ARG, "overlap_loss: null pointer");
     if (ncls < 2 || ncls > OUTC_MAXCLS) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: ncls=%d unsupported (2..%d)", ncls, OUTC_MAXCLS);
-    if (B <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: bad shape");
+    if (B <= 0 || H <= 0 || W <= 0 || (size_t)B * H * W >= ((size_t)1 << 31)) BDN_FAIL(BDN_E_SHAPE, "overlap_loss: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const OverlapPlan p = overlap_plan(B, ncls, H, W, reduce_w);
     const int We = p.We;
     float* part = ws + p.n;                                                    // [nblk][n] block partials behind the n final sums
     int32_t* pcounts = reinterpret_cast<int32_t*>(part + (size_t)p.nblk * p.n);  // [gx*gy][4]
     dim3 grid(p.gx, p.gy), block(p.RL, p.CW);
-    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, part, pcounts, B, ncls, H, W, p.rpb, We);
-    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, part, pcounts, B, ncls, H, W, p.rpb, We);
+    if (ncls <= 2) hipLaunchKernelGGL(tversky_sums_kernel<2>, grid, block, sizeof(float) * 256 * 3 * 2, st, logits, labels, part, pcounts, B, ncls, H, W, p.rpb, We, FastDiv(H));
+    else hipLaunchKernelGGL(tversky_sums_kernel<OUTC_MAXCLS>, grid, block, sizeof(float) * 256 * 3 * OUTC_MAXCLS, st, logits, labels, part, pcounts, B, ncls, H, W, p.rpb, We, FastDiv(H));
     BDN_CHECK_LAUNCH("tversky_sums");
     hipLaunchKernelGGL(tversky_finish_kernel, dim3(1), dim3(1024), 0, st, ws, part, p.nblk, pcounts, p.gx * p.gy, counts, alpha, beta, eps, ncls, We, loss);
     BDN_CHECK_LAUNCH("tversky_finish");
     if (dlogits) {
-        hipLaunchKernelGGL(tversky_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, logits, labels, ws, alpha, beta, dlogits, B, ncls, H, W, We);
+        hipLaunchKernelGGL(tversky_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, logits, labels, ws, alpha, beta, dlogits, B, ncls, H, W, We, FastDiv(H * W), FastDiv(W));
         BDN_CHECK_LAUNCH("tversky_bwd");
     }
     return BDN_OK;
