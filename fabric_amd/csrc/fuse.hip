@@ -430,7 +430,9 @@ __global__ __launch_bounds__(UB == 8 ? 512 : 256) void upsample2x_bwd_tiled_kern
     constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, PSTR = UB * 16 + 16, NT = 64 * UB;      // one thread per (source pixel, unit)
     __shared__ __attribute__((aligned(16))) unsigned char sm[R * R * PSTR];
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    // neighbouring tiles share 4 of their 20 window rows / columns: consecutive tiles stay on one XCD so that the overlap is an L2 hit
+    // (round-robin over the XCDs every tile fetched its whole window from memory: 1.5x the gradient's bytes in the PMC table)
+    const int tile = xcd_remap(blockIdx.x, gridDim.x), tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int c0 = blockIdx.y * UB * EPU;
     const int ys0 = ty * TS, xs0 = tx * TS;
     const int top = (H - 2 * h) / 2, left = (W - 2 * w) / 2;
