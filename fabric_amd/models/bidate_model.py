@@ -129,3 +129,19 @@ class BiDateNet(nn.Module):
         d = self.__dict__.copy()
         d['_engine'] = None
         return d
+
+    def __setstate__(self, state):
+        """Unpickling.  The reference persists a model ONLY as a whole-module pickle (train.py:222 `torch.save(model, ...)` of
+        nn.DataParallel(BiDateNet(13, 2)), utils/helpers.py:333-335).  Such a pickle resolves its class paths to this class through the
+        root `models.*` shims, but its __dict__ is the reference's: sub-modules and parameters only.  Everything this class adds is
+        derived state and is rebuilt here: the channel counts from the first / last convolution, the numerics setting from
+        BIDATE_PRECISION (default 'bf16'), no engine yet."""
+        super().__setstate__(state)
+        d = self.__dict__
+        if 'n_channels' not in d:
+            d['n_channels'] = int(self.inc.conv.conv[0].weight.shape[1])
+        if 'n_classes' not in d:
+            d['n_classes'] = int(self.outc.conv.weight.shape[0])
+        if d.get('precision') is None:
+            d['precision'] = os.environ.get('BIDATE_PRECISION', 'bf16')
+        d['_engine'] = None

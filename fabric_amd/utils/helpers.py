@@ -1,6 +1,7 @@
 """Glue with the reference's names and semantics (utils/helpers.py:24-89, 288-337) for the parts the
 train step needs: running-mean metric dicts, criterion factory, model factory."""
 import numpy as np
+import torch
 
 from ..models.bidate_model import BiDateNet
 from .metrics import FocalLoss, TverskyLoss, dice_loss, jaccard_loss
@@ -46,3 +47,48 @@ def load_model(opt, device, precision=None):
     """reference utils/helpers.py:317-337 builds nn.DataParallel(BiDateNet(13, 2)); here one process drives one
     GPU and gradients are exchanged by fabric_amd.parallel (RCCL), so the bare module is returned."""
     return BiDateNet(13, 2, precision=precision).to(device)
+
+
+def strip_module_prefix(state_dict):
+    """State dict saved from the reference's nn.DataParallel wrapper (utils/helpers.py:335): every key carries `module.`.
+    Returns a dict with the prefix removed from the keys that have it (a bare-module state dict passes through unchanged)."""
+    return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+
+
+def load_checkpoint(src, device=None, precision=None):
+    """A usable BiDateNet from anything the reference (or fabric_amd.train) leaves behind.
+
+    `src` is a path / file object for torch.load, or an object already loaded:
+      * the whole-module pickle of train.py:222 -- nn.DataParallel(BiDateNet) or a bare BiDateNet (the class paths
+        `models.bidate_model.BiDateNet`, `models.unet_parts.*` resolve through the repo-root shims; run with the repo root on
+        sys.path).  The DataParallel wrapper is dropped: here one process drives one GPU (fabric_amd.parallel);
+      * a state dict, with or without the `module.` prefix of a DataParallel save, optionally nested under 'state_dict' / 'model'.
+    The result is always a fresh fabric_amd BiDateNet carrying the checkpoint's parameters AND BatchNorm buffers; the channel
+    counts come from the tensors.  Mismatched / missing / unexpected keys raise (load_state_dict(strict=True))."""
+    obj = src
+    if isinstance(src, (str, bytes)) or hasattr(src, 'read') or hasattr(src, '__fspath__'):
+        # a whole-module pickle needs the unpickler, not the tensors-only loader
+        obj = torch.load(src, map_location='cpu', weights_only=False)
+    if isinstance(obj, torch.nn.DataParallel) or (isinstance(obj, torch.nn.Module) and hasattr(obj, 'module')
+                                                  and not isinstance(obj, BiDateNet)):
+        obj = obj.module
+    if isinstance(obj, torch.nn.Module):
+        sd = obj.state_dict()
+    elif isinstance(obj, dict):
+        sd = obj
+        for nest in ('state_dict', 'model'):
+            if nest in sd and isinstance(sd[nest], dict):
+                sd = sd[nest]
+            elif nest in sd and isinstance(sd[nest], torch.nn.Module):
+                return load_checkpoint(sd[nest], device, precision)
+    else:
+        raise TypeError(f'fabric_amd: cannot load a checkpoint from {type(obj).__name__}')
+    sd = strip_module_prefix(sd)
+    try:
+        n_channels = int(sd['inc.conv.conv.0.weight'].shape[1])
+        n_classes = int(sd['outc.conv.weight'].shape[0])
+    except KeyError as e:
+        raise RuntimeError(f'fabric_amd: not a BiDateNet checkpoint (missing {e.args[0]!r})') from None
+    model = BiDateNet(n_channels, n_classes, precision=precision)
+    model.load_state_dict(sd, strict=True)
+    return model.to(device) if device is not None else model

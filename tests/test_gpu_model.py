@@ -195,3 +195,31 @@ def test_f1_definition_on_device_counts(golden_dir):
     assert abs(loss.item() - float(g['loss'])) < 1e-5
     p, r, f = batch_prf_from_counts(crit.last_counts)
     assert np.allclose([p, r, f], g['prf'], atol=2e-3)
+
+
+def test_model_loaded_from_a_reference_style_pickle_reproduces_g1(golden_dir, monkeypatch):
+    """SURVEY.md 8b, reference train.py:222: a whole-module pickle of DataParallel(BiDateNet) WITHOUT the attributes this build adds
+    (what a reference-written file holds after its class paths resolve through the root shims) is loaded by load_checkpoint AND used
+    directly after torch.load(...).module; both reproduce golden G1 (train-mode logits within 1e-3, loss within 1e-5)."""
+    import io
+    import models.bidate_model as shim
+    from fabric_amd.models.bidate_model import BiDateNet as B
+    from fabric_amd.utils.helpers import load_checkpoint
+    g, c, x1, x2, lbl = _load(golden_dir, 'g1_c3_b4_s32')
+    added = ('_engine', 'precision', 'n_channels', 'n_classes')
+    monkeypatch.setattr(B, '__getstate__', lambda self: {k: v for k, v in self.__dict__.items() if k not in added})
+    buf = io.BytesIO()
+    torch.save(torch.nn.DataParallel(filler.fill_module(shim.BiDateNet(c, 2))), buf)
+    monkeypatch.undo()
+    ref = torch.from_numpy(g['logits'])
+    monkeypatch.setenv('BIDATE_PRECISION', 'fp32')            # a reference pickle carries no numerics setting: the environment decides
+    raw = torch.load(io.BytesIO(buf.getvalue()), weights_only=False).module.cuda().train()
+    loaded = load_checkpoint(io.BytesIO(buf.getvalue()), device='cuda', precision='fp32').train()
+    for m in (raw, loaded):
+        assert m.precision == 'fp32' and m.n_channels == c
+        logits = m(x1, x2)
+        loss = _tversky_torch(logits, lbl)
+        loss.backward()
+        assert (logits.detach().cpu() - ref).abs().max() <= 1e-3
+        assert abs(loss.item() - float(g['loss'])) < 1e-5
+        assert int(m.state_dict()['inc.conv.conv.1.num_batches_tracked']) == 2

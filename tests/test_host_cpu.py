@@ -90,8 +90,91 @@ def test_state_dict_schema_matches_reference():
     assert sd['up1.conv.conv.0.weight'].shape == (256, 1024, 3, 3)
     order = param_order(13)
     assert set(order) == {k for k, _ in m.named_parameters()} and len(order) == 74
-    # a DataParallel-style checkpoint ('module.' prefix, reference train.py:222) loads after stripping the prefix
-    m.load_state_dict({k[len('module.'):]: v for k, v in {('module.' + k): v for k, v in ref.items()}.items()})
+
+
+def _reference_like_pickle(model, monkeypatch):
+    """Bytes of torch.save(nn.DataParallel(model)) as the REFERENCE would have written them (train.py:222): the BiDateNet state
+    holds sub-modules and parameters only -- none of the attributes this build adds (_engine, precision, n_channels, n_classes)."""
+    import io
+    from fabric_amd.models.bidate_model import BiDateNet
+    added = ('_engine', 'precision', 'n_channels', 'n_classes')
+    monkeypatch.setattr(BiDateNet, '__getstate__', lambda self: {k: v for k, v in self.__dict__.items() if k not in added})
+    buf = io.BytesIO()
+    torch.save(torch.nn.DataParallel(model), buf)
+    monkeypatch.undo()
+    return buf.getvalue()
+
+
+def test_reference_whole_module_pickle_loads_into_a_usable_model(monkeypatch):
+    """SURVEY.md 8b / reference train.py:222: the reference persists torch.save(DataParallel(BiDateNet)).  Unpickling resolves the class
+    paths through the root `models.*` shims; __setstate__ rebuilds what the reference never had; load_checkpoint unwraps the
+    DataParallel and returns a model whose engine() can be built."""
+    import io
+    import models.bidate_model as shim                        # the reference's import path
+    from fabric_amd.utils.helpers import load_checkpoint
+    from oracle import filler
+    src = filler.fill_module(shim.BiDateNet(3, 2))
+    blob = _reference_like_pickle(src, monkeypatch)
+    assert b'_engine' not in blob and b'precision' not in blob and b'n_classes' not in blob
+    obj = torch.load(io.BytesIO(blob), weights_only=False)
+    inner = obj.module
+    assert type(inner).__name__ == 'BiDateNet' and inner._engine is None
+    assert (inner.n_channels, inner.n_classes, inner.precision) == (3, 2, os.environ.get('BIDATE_PRECISION', 'bf16'))
+    assert inner.engine().layers[0].cin_real == 3              # the engine builds (raises if the HIP library is missing)
+    m = load_checkpoint(io.BytesIO(blob), precision='fp32')
+    assert (m.n_channels, m.n_classes, m.precision) == (3, 2, 'fp32') and not isinstance(m, torch.nn.DataParallel)
+    sd, ref = m.state_dict(), src.state_dict()
+    assert list(sd) == list(ref) and all(torch.equal(sd[k], ref[k]) for k in ref)
+    # a 13-band pickle derives 13
+    blob13 = _reference_like_pickle(shim.BiDateNet(13, 2), monkeypatch)
+    assert torch.load(io.BytesIO(blob13), weights_only=False).module.n_channels == 13
+
+
+def test_module_prefixed_state_dict_loads():
+    """A state dict saved from the reference's DataParallel wrapper carries `module.` on every key (helpers.py:335): a plain
+    load_state_dict rejects it, load_checkpoint takes it (and the bare and nested forms) and keeps the BatchNorm buffers."""
+    from fabric_amd import BiDateNet
+    from fabric_amd.utils.helpers import load_checkpoint, strip_module_prefix
+    from oracle import filler
+    src = filler.fill_module(BiDateNet(13, 2))
+    ref = src.state_dict()
+    prefixed = {'module.' + k: v.clone() for k, v in ref.items()}
+    with pytest.raises(RuntimeError, match='Missing key|Unexpected key'):
+        BiDateNet(13, 2).load_state_dict(prefixed)
+    assert list(strip_module_prefix(prefixed)) == list(ref)
+    for form in (prefixed, dict(ref), {'state_dict': prefixed}, {'model': torch.nn.DataParallel(src)}, src):
+        m = load_checkpoint(form)
+        sd = m.state_dict()
+        assert m.n_channels == 13 and list(sd) == list(ref) and all(torch.equal(sd[k], ref[k]) for k in ref)
+        assert sd['inc.conv.conv.1.num_batches_tracked'].dtype == torch.int64
+    bad = dict(prefixed)
+    del bad['module.up3.conv.conv.4.running_var']
+    with pytest.raises(RuntimeError, match='running_var'):
+        load_checkpoint(bad)
+    with pytest.raises(RuntimeError, match='not a BiDateNet checkpoint'):
+        load_checkpoint({'foo': torch.zeros(1)})
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/models'), reason='the reference tree is only present in the build container')
+def test_genuine_reference_pickle_loads(tmp_path):
+    """The real thing where the reference is at hand: a separate interpreter imports the REFERENCE's BiDateNet, wraps it as
+    utils/helpers.py:333-335 does and saves it as train.py:222 does; this process (repo root on sys.path) loads the file."""
+    import subprocess
+    from fabric_amd.utils.helpers import load_checkpoint
+    out = tmp_path / 'checkpoint_epoch_0.pt'
+    code = ('import sys, torch; sys.path.insert(0, "/root/reference"); torch.manual_seed(3);'
+            'from models.bidate_model import BiDateNet; import torch.nn as nn;'
+            f'm = nn.DataParallel(BiDateNet(3, 2)); torch.save(m, r"{out}"); torch.save(m.state_dict(), r"{out}.sd")')
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=str(tmp_path))
+    obj = torch.load(str(out), weights_only=False)
+    assert type(obj.module).__module__ == 'fabric_amd.models.bidate_model' and obj.module.engine() is not None
+    m = load_checkpoint(str(out))
+    sd = torch.load(str(out) + '.sd')
+    assert all(k.startswith('module.') for k in sd)
+    got = m.state_dict()
+    assert len(got) == 128 and all(torch.equal(got[k], sd['module.' + k]) for k in got)
+    m2 = load_checkpoint(str(out) + '.sd')
+    assert all(torch.equal(m2.state_dict()[k], got[k]) for k in got)
 
 
 def test_modules_refuse_cpu_and_have_no_fallback():
