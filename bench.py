@@ -505,6 +505,7 @@ def main():
                     help='N=1 only: the HEADLINE loop itself issues its gradient-bucket all-reduces through RCCL (world size 1)')
     ap.add_argument('--windows', type=int, default=3,
                     help='consecutive timed windows of --steps steps each; the headline is the MEDIAN window (all are reported)')
+    ap.add_argument('--engine-set', default='', help='A/B runs only: engine attributes for the headline loop, e.g. fwd_chains=1,defer_product=0')
     ap.add_argument('--launcher-selftest', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -575,6 +576,11 @@ def main():
     torch.cuda.set_stream(ts.stream())       # the loop runs on the step's own high-priority stream, as fabric_amd/train.py's does:
                                              # no cross-stream joins at the step boundaries (~25 us of idle GPU per step)
     eng = model.engine()
+    for item in filter(None, args.engine_set.split(',')):
+        k_, v_ = item.split('=')
+        if not hasattr(eng, k_):
+            raise SystemExit(f'--engine-set: the engine has no attribute {k_!r}')
+        setattr(eng, k_, int(v_) if v_.lstrip('-').isdigit() else v_)
     for _ in range(args.warmup):
         ts.step(x1, x2, lbl)
     # Which MFMA kernel (conv3x3 instantiation or weight-gradient GEMM) dominates?  One fully instrumented, UNTIMED step decides

@@ -130,6 +130,7 @@ class Workspace:
                     n_wg = max(n_wg, lib.bdn_wgrad_workspace_bytes_ex(eng.dt, n, hk, wk, L.cout, L.cin, 0, ipg, IN_PLAIN, wg_flags(3, 0, blocks)) // 4)
         self.stats = f32(n_stats)
         self.bnws = torch.empty(2 * 64 * 2 * 1024, dtype=torch.float64, device=device)
+        self._chain2 = None        # (stats, bnws) of the second forward chain, allocated when the two-chain forward first runs
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
         self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, 256)) // 4
@@ -155,6 +156,13 @@ class Workspace:
         """bf16x3: drop the per-layer operand-split buffers (at B=16, 128x128 about 1.5 GB per workspace that has trained).  They are
         re-grown on demand by the next training forward; an eval-only phase after training calls this (BiDateNet.eval() does)."""
         self._split = {}
+
+    def chain2(self):
+        """Per-tile statistics buffer and finalize scratch of the forward's second chain (date 2 on its own stream): the two chains'
+        convolutions are in flight at once, so they cannot share ws.stats / ws.bnws."""
+        if self._chain2 is None:
+            self._chain2 = (torch.empty_like(self.stats), torch.empty_like(self.bnws))
+        return self._chain2
 
     def outc_ws(self, eng):
         """Scratch of bdn_outc_bwd (per-block partial classifier gradients)."""
@@ -204,6 +212,16 @@ class BiDateEngine:
         # layers (64 output channels) whose BatchNorm backward is applied inside their data-gradient conv (bdn_conv3x3_dgrad_bb) instead of by the
         # bn_bwd_apply pass.  In-process A/B (tools/ab_fold.py): e1b -0.6 % step time, d4a +0.4 %, d3a+d3b +0.5 % -- only e1b is folded
         self.fold_bn_bwd = ('e1b',)
+        # forward schedule (tools/ab_flag.py).  fwd_chains = 2: the two dates go through encoder levels 1..fwd_chain_levels as two B-image chains on
+        # two streams (the BatchNorm groups are per date already, so tables and bits do not change): one date's convolutions cover the
+        # other's statistics reductions / finalizes / pooling; the chains join where the skip product needs both dates.
+        # defer_product = 1: at the split levels each chain pools its own date (bdn_bnrelu_pool) and the skip products f_k run on the
+        # second stream beside encoder levels 4-5 (they are first read by the decoder).
+        self.fwd_chains = 1
+        self.fwd_chain_levels = 3
+        self.defer_product = 1
+        self.fwd_chain2_role = 'chain2'
+        self._fwd_handoffs = {}
         self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
@@ -309,10 +327,20 @@ class BiDateEngine:
                 if not ws.leased:
                     ws.release_split()
 
-    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st, reuse_eval_bn=False, presplit=False):
+    def _conv(self, ws, L, P, in0, c0, in1, c1, in_mode, in_bn, n, ipg, training, st, reuse_eval_bn=False, presplit=False,
+              date=None, before_finalize=None, after_finalize=None):
+        """One conv3x3 + BatchNorm statistics stage.  date = 0 / 1: the launch covers ONE date's B images of an encoder layer (two-chain
+        forward): its slice of z, its row of the BatchNorm table, and -- for date 1, whose launches run beside date 0's -- the second
+        chain's statistics buffers.  before_finalize / after_finalize: callables around the finalize launch (the running statistics
+        see date 0 then date 1, so date 1's finalize is ordered behind date 0's)."""
         hk, wk = ws.dims[L.level - 1]
         wf, _ = self._weights(L, P, False)
         z = ws.z[L.name]
+        stats, bnws, bn = ws.stats, ws.bnws, ws.bn[L.name]
+        if date is not None:
+            z, bn = z[date * n:(date + 1) * n], bn[date:date + 1]
+            if date == 1:
+                stats, bnws = ws.chain2()
         if self.x3:
             # the operand split does the cat and the BatchNorm+ReLU the f32 kernel would apply on load
             # training: one buffer per layer, kept for the layer's weight-gradient GEMM (the same operand: no second split in backward)
@@ -322,16 +350,19 @@ class BiDateEngine:
             in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
         self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
                          self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
-                         ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(ws.stats) if training else None,
+                         ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(stats) if training else None,
                          n, hk, wk, L.cout, st)
-        bn = ws.bn[L.name]
         G = n // ipg
         if training:
             nt = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg)
-            call('bdn_bn_finalize', ptr(ws.stats), nt, G, L.cout, ipg * hk * wk,
+            if before_finalize is not None:
+                before_finalize()
+            call('bdn_bn_finalize', ptr(stats), nt, G, L.cout, ipg * hk * wk,
                  ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']), BN_EPS, BN_MOMENTUM,
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']),
-                 ptr(P[f'{L.bn}.num_batches_tracked']), ptr(bn), ptr(ws.bnws), st)
+                 ptr(P[f'{L.bn}.num_batches_tracked']), ptr(bn), ptr(bnws), st)
+            if after_finalize is not None:
+                after_finalize()
         elif not reuse_eval_bn:
             call('bdn_bn_eval', ptr(P[f'{L.bn}.weight']), ptr(P[f'{L.bn}.bias']),
                  ptr(P[f'{L.bn}.running_mean']), ptr(P[f'{L.bn}.running_var']), BN_EPS, G, L.cout, ptr(bn), st)
@@ -390,8 +421,12 @@ class BiDateEngine:
             # invalidate_weights() after such an update (BiDateNet.load_state_dict / _apply do it themselves).
             self._packed_valid = False
         rb = reuse_eval_bn and not training
+        k_first = 1
+        deferred = None
+        if self.fwd_chains == 2 and training and not self.x3:
+            k_first, deferred = self._encoder_two_chains(ws, P, by, st)
         # ---- shared encoder on both dates (2B images, 2 statistic groups)
-        for k in range(1, 6):
+        for k in range(k_first, 6):
             hk, wk = ws.dims[k - 1]
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
             src = ws.x0 if k == 1 else ws.pool[k]           # pool[k] was written together with the skip of level k-1
@@ -421,6 +456,9 @@ class BiDateEngine:
             else:
                 call('bdn_upsample2x', self.dt, ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.U[j]),
                      B, hs, wsrc, hk, wk, cprev, st)
+            if deferred is not None and k <= deferred[0]:
+                deferred[1].wait(torch.cuda.current_stream(dev))     # the skip products of the split levels were left on the second stream
+                deferred = None
             za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st, rb, presplit=pre)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st, rb)
             prev, prev_bn, prev_mode, cprev = zb, bnb, IN_BNRELU, Lb.cout
@@ -428,6 +466,79 @@ class BiDateEngine:
         call('bdn_outc_fwd', self.dt, ptr(prev), ptr(prev_bn), ptr(P['outc.conv.weight']), ptr(P['outc.conv.bias']),
              ptr(logits), B, H, W, cprev, self.n_classes, st)
         return logits
+
+    def _fwd_handoff(self, dev, i):
+        pool = self._fwd_handoffs.setdefault(dev.index, [])
+        while len(pool) <= i:
+            from .streams import HandOff
+            with torch.cuda.device(dev):
+                pool.append(HandOff())
+        return pool[i]
+
+    def _encoder_two_chains(self, ws, P, by, st):
+        """Encoder levels 1..fwd_chain_levels with the two dates as two independent B-image chains: date 0 on the current (chain) stream,
+        date 1 on a second stream.  The reference runs the dates one after the other through the same modules (models/bidate_model.py:23-33);
+        here they were one 2B batch with two statistic groups -- the split changes no arithmetic (same tiles, same per-group reductions) but
+        lets one date's convolutions run while the other's dependent reduce / finalize / pool launches drain.  Ordering kept by events:
+        the running statistics and num_batches_tracked are updated by date 0's finalize first, then by date 1's (reference order).
+        Returns (first level the joined schedule continues with, deferred-product hand-off or None)."""
+        from . import streams
+        B = ws.B
+        dev = ws.x0.device
+        main = torch.cuda.current_stream(dev)
+        second = streams.get(self.fwd_chain2_role, dev)
+        Lmax = max(1, min(4, self.fwd_chain_levels))
+        ev = [0]
+
+        def new_ev():
+            ev[0] += 1
+            return self._fwd_handoff(dev, ev[0] - 1)
+
+        start = new_ev()
+        start.signal(main)                                   # packed input and packed weights are ready
+        start.wait(second)
+        chains = ((0, main, st), (1, second, second.cuda_stream))
+        fin_events = {}
+        for k in range(1, Lmax + 1):
+            hk, wk = ws.dims[k - 1]
+            La, Lb = by[f'e{k}a'], by[f'e{k}b']
+            src = ws.x0 if k == 1 else ws.pool[k]
+            for L in (La, Lb):
+                fin_events[L.name] = new_ev()
+            for d, stream, sp in chains:
+                with torch.cuda.stream(stream):
+                    def order(L, d=d, stream=stream):
+                        if d == 0:
+                            return dict(after_finalize=lambda: fin_events[L.name].signal(stream))
+                        return dict(before_finalize=lambda: fin_events[L.name].wait(stream))
+                    za, bna = self._conv(ws, La, P, src[d * B:(d + 1) * B], La.cin, None, 0, IN_PLAIN, None, B, B, True, sp, date=d, **order(La))
+                    zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, True, sp, date=d, **order(Lb))
+                    if self.defer_product or k < Lmax:
+                        # each chain pools its own date; the skip product follows off the critical path (or at the join)
+                        call('bdn_bnrelu_pool', self.dt, ptr(zb), ptr(bnb), B, ptr(ws.pool[k + 1][d * B:(d + 1) * B]), B, hk, wk, ENC_CH[k - 1], sp)
+        join = new_ev()
+        join.signal(second)
+        join.wait(main)
+        # ---- skip products of the split levels: need both dates
+        def products(sp, levels):
+            for k in levels:
+                hk, wk = ws.dims[k - 1]
+                Lb = by[f'e{k}b']
+                call('bdn_fuse_product', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], sp)
+        if self.defer_product:
+            back = new_ev()
+            back.signal(main)                                # date 0's z of the last split level
+            back.wait(second)
+            with torch.cuda.stream(second):
+                products(second.cuda_stream, range(Lmax, 0, -1))     # the decoder needs f_Lmax first
+            done = new_ev()
+            done.signal(second)
+            return Lmax + 1, (Lmax, done)
+        hk, wk = ws.dims[Lmax - 1]
+        Lb = by[f'e{Lmax}b']
+        call('bdn_product_pool', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[Lmax]), ptr(ws.pool[Lmax + 1]), B, hk, wk, ENC_CH[Lmax - 1], st)
+        products(st, range(Lmax - 1, 0, -1))
+        return Lmax + 1, None
 
     # ------------------------------------------------------------------ backward
     def backward(self, ws, dlogits, P, grads, on_ready=None, zero_bias_grads=True, wgrad_stream=True):
