@@ -19,6 +19,9 @@ Extra objects on the same line:
   mfma_ceiling   a bare MFMA loop on zero and on random bf16 operands: the data-dependent (power-bound) ceiling of the matrix cores;
   host_fed       the same step fed from pinned HOST memory through fabric_amd.input_pipeline.DeviceFeeder (PCIe inclusive);
   parity_setting pairs/s of the two float32-class settings (bf16x3: logits within 1e-3; fp32: exact f32 MFMA);
+  val_f1         the second half of BASELINE.json's metric: tail training F1 and held-out validation F1 of a 60-step synthetic change-blob
+                 run in the fp32, bf16x3 and bf16 settings, and |dF1| against fp32;
+  conv3d         BASELINE configs[3] shapes: DoubleConv3d (3x3x3) forward + backward at 2 x 5 x 13 x 128 x 128 (parity unpinned);
   scene          BASELINE configs[4]: full-scene sliding-window inference of a 13-band 10000 x 10000 scene pair, resident in HBM and
                  (scene.host_fed) streamed from pinned host memory under the compute.
 """
@@ -53,7 +56,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(search_budget=30.0, confirm_budget=60.0):
+def cpu_baseline(search_budget=30.0, confirm_budget=75.0):
     """Reference CPU path (oracle port) on the host cores: fwd + Tversky + bwd + SGD, fp32 (B=16 and B=4, median of
     >= 5 timed steps after warm-up).  Phase 1 searches the thread count with short runs at B=16 -- "all cores" is tried, but so are
     smaller counts: stock torch/oneDNN gets SLOWER past one thread per physical core on the big two-socket hosts (256 logical CPUs:
@@ -78,10 +81,12 @@ def cpu_baseline(search_budget=30.0, confirm_budget=60.0):
         loss.backward()
         opt.step()
 
-    def timed(batch, n, budget):
+    def timed(batch, n, budget, warmups=2):
         t_begin = time.perf_counter()
-        step(batch)                                   # warm-up (oneDNN primitive creation for this thread count / shape)
-        warm = time.perf_counter() - t_begin
+        for _ in range(warmups):                      # warm-up (oneDNN primitive creation for this thread count / shape); BASELINE.md section 3: two
+            t_w = time.perf_counter()
+            step(batch)
+            warm = time.perf_counter() - t_w
         times = []
         while len(times) < n and (not times or time.perf_counter() - t_begin + times[-1] < budget):
             t0 = time.perf_counter()
@@ -104,7 +109,7 @@ def cpu_baseline(search_budget=30.0, confirm_budget=60.0):
             tried.append((th, None, 0))
             continue
         torch.set_num_threads(th)
-        t, n = timed(b16, 2, max(left, 1.0))
+        t, n = timed(b16, 2, max(left, 1.0), warmups=1)     # the search only ranks thread counts; the confirm runs below warm up twice
         tried.append((th, t, n))
     best_th = min((t for t in tried if t[1] is not None), key=lambda t: t[1])[0]
     torch.set_num_threads(best_th)
@@ -116,7 +121,7 @@ def cpu_baseline(search_budget=30.0, confirm_budget=60.0):
             'timed_steps': n16, 'ms_per_step': t16 * 1e3,
             'sample': f'13x128x128 fwd+Tversky+bwd+SGD steps, fp32 stock torch.nn assembly of the reference graph (oracle.build_torch_baseline, '
                       f'pinned to the golden logits by tests/test_oracle_cpu.py): median of {n16} timed steps at B=16 (value) and of {n4} at B=4 (b4) '
-                      f'after one warm-up step each, at the fastest thread count of a short search; host has {ncores} usable CPUs '
+                      f'after two warm-up steps each (BASELINE.md section 3), at the fastest thread count of a short search (one warm-up + up to 2 steps per count); host has {ncores} usable CPUs '
                       f'({_cpu_model()}); search at B=16: {listing}'}
 
 
@@ -175,6 +180,42 @@ def rocprof_avg_us(kernel, precision):
         if r['Name'].startswith(key):
             return float(r['AverageNs']) / 1e3, os.path.relpath(path, ROOT)
     return None, os.path.relpath(path, ROOT)
+
+
+def family_of(kernel):
+    """Kernel FAMILY of an instantiation name: every conv3x3_kernel<...> instantiation is one kernel with different tile constants,
+    wgrad7_kernel<true> / <false> one kernel with a bool (round-4 review: the dominant consumer must not hide behind a template split)."""
+    return kernel.split('<')[0] + '<*>' if '<' in kernel else kernel
+
+
+def rocprof_family_avg_us(names, precision):
+    """Launch-weighted average duration over the instantiations `names` in the newest committed kernel-stats summary."""
+    path = _latest('r*_kernel_stats.csv')
+    if precision != 'bf16' or not path:
+        return None, None
+    keys = ['void ' + _kkey(n) for n in names]
+    calls = tot = 0.0
+    for r in csv.DictReader(open(path)):
+        if any(r['Name'].startswith(k) for k in keys):
+            calls += float(r['Calls']); tot += float(r['TotalDurationNs'])
+    return (tot / calls / 1e3 if calls else None), os.path.relpath(path, ROOT)
+
+
+def pmc_family_traffic(names, per_step_launches, precision):
+    """HBM bytes per launch of a family: launch-weighted mean over its instantiations in the committed PMC summary."""
+    tab, path = pmc_tables(precision)
+    if not tab:
+        return None
+    rd = wr = n = 0.0
+    for nm in names:
+        tr = pmc_traffic(nm, precision)
+        if tr is None:
+            return None
+        k = per_step_launches[nm]
+        rd += tr['hbm_read'] * k; wr += tr['hbm_write'] * k; n += k
+    return {'unit': 'bytes/launch', 'hbm_read': rd / n, 'hbm_write': wr / n, 'source': os.path.relpath(path, ROOT),
+            'correction': 'FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported; separate --pmc passes; '
+                          'launch-weighted mean over the family\'s instantiations'}
 
 
 def mfma_ceiling():
@@ -435,6 +476,95 @@ def scene_leg(dev, size=10000, batch=256, reps=2, band_rows=None):
     return out
 
 
+def val_f1_leg(dev, steps=60, B=8, S=128, lr=0.02):
+    """The other half of BASELINE.json's metric ("...; val F1"): does the benchmarked bf16 setting reach the same F1 as the float32 one?
+    Synthetic OSCD-shaped scenes with change blobs (fabric_amd.utils.dataloaders.synthetic_onera: four 13-band 300 x 300 cities), `steps`
+    fused train steps at batch `B` from identical random-init weights in each numerics setting on cities 0-2; reported per setting: the
+    training loss / per-batch F1 averaged over the last 10 steps, and the VALIDATION F1 on the held-out city 3 with the reference's
+    definitions (eval-mode forward, train.py:125-172; per-batch sklearn-style binary P/R/F1, utils/helpers.py:45-59 mean over batches)."""
+    import numpy as np
+    from fabric_amd import BiDateNet
+    from fabric_amd.train import validate
+    from fabric_amd.train_step import TrainStep
+    from fabric_amd.utils.dataloaders import OneraPreloader, metadata_from_shapes, patch_origins, synthetic_onera
+    from fabric_amd.utils.metrics import TverskyLoss, batch_prf_from_counts
+    data = synthetic_onera(n_cities=4, bands=13, size=(300, 300), seed=5, change_fraction=0.15)
+    cities = sorted(data)
+    items = [(c, i, j) for c in cities[:3] for i, j in patch_origins(300, 300, S, 43)]
+    order = np.random.default_rng(9).permutation(len(items))
+    batches = []
+    for st in range(steps):
+        pick = [items[order[(st * B + k) % len(items)]] for k in range(B)]
+        x = np.stack([data[c]['images'][:, :, i:i + S, j:j + S] for c, i, j in pick])
+        y = np.stack([data[c]['labels'][i:i + S, j:j + S] for c, i, j in pick])
+        batches.append((torch.from_numpy(x[:, 0].copy()).to(dev), torch.from_numpy(x[:, 1].copy()).to(dev), torch.from_numpy(y.copy()).to(dev)))
+    val_meta = [[cities[3], i, j] for i, j in patch_origins(300, 300, S, 43)]
+    val_ds = OneraPreloader('', val_meta, data, S, False)
+    val_loader = torch.utils.data.DataLoader(val_ds, batch_size=B, shuffle=False)
+    torch.manual_seed(1234)
+    sd0 = {k: v.clone() for k, v in BiDateNet(13, 2).state_dict().items()}
+    out = {}
+    for prec in ('fp32', 'bf16x3', 'bf16'):
+        m = BiDateNet(13, 2, precision=prec)
+        m.load_state_dict(sd0)
+        m = m.to(dev).train()
+        ts = TrainStep(m, lr=lr, tversky_alpha=0.1, tversky_beta=0.9)
+        recs = []
+        for x1, x2, y in batches:
+            loss = ts.step(x1, x2, y)
+            recs.append((loss, ts.last_counts.clone()))
+        losses = [float(l.item()) for l, _ in recs]
+        f1s = [batch_prf_from_counts(c.cpu())[2] for _, c in recs]
+        v = validate(m, val_loader, dev, S, TverskyLoss(alpha=0.1, beta=0.9))
+        out[prec] = {'first_loss': losses[0], 'tail_loss': float(np.mean(losses[-10:])), 'tail_train_f1': float(np.mean(f1s[-10:])),
+                     'val_f1': float(v['cd_f1scores']), 'val_precision': float(v['cd_precisions']), 'val_recall': float(v['cd_recalls']),
+                     'val_loss': float(v['cd_losses'])}
+        del ts, m
+        torch.cuda.empty_cache()
+    for prec in ('bf16x3', 'bf16'):
+        out[prec]['abs_dF1_vs_fp32'] = {'val': abs(out[prec]['val_f1'] - out['fp32']['val_f1']),
+                                        'tail_train': abs(out[prec]['tail_train_f1'] - out['fp32']['tail_train_f1'])}
+    out['workload'] = (f'{steps} fused train steps, batch {B}, 13-band {S}x{S} patches cut from 3 synthetic change-blob cities (lr {lr}, Tversky 0.1/0.9), '
+                       f'then eval-mode validation on {len(val_ds)} patches of a held-out city; identical init and batch order in every setting')
+    out['definition'] = 'val_f1 = mean over validation batches of the binary F1 of argmax(logits) (reference train.py:150-160, utils/helpers.py:45-59)'
+    out['data'] = 'synthetic (no OSCD download in this environment): F1 parity BETWEEN numerics settings, not an OSCD score'
+    return out
+
+
+def conv3d_leg(dev, N=2, D=5, S=128, cin=13, cout=64, iters=5):
+    """BASELINE.json configs[3] (multi-date stack, 5 dates x 13 bands x 128 x 128) as far as a reference exists for it -- it does not
+    (UNetLSTM/ is an empty sub-module), so PARITY IS UNPINNED: the 3x3x3 `DoubleConv3d` block (tests/test_gpu_conv3d.py checks it against
+    torch.nn.Conv3d / BatchNorm3d) forward + backward at N x 5 x 13 x 128 x 128, and the same for the 64 -> 64 block that follows it."""
+    from fabric_amd.conv3d import DoubleConv3d
+    out = {'workload': f'DoubleConv3d forward + backward, {N} samples of {D} dates x {cin} bands x {S} x {S}, bf16 (BASELINE configs[3] shapes)',
+           'parity': 'unpinned: the reference holds no 3-D model source; block checked against torch.nn in tests/test_gpu_conv3d.py'}
+    for ci, co in ((cin, cout), (cout, cout)):
+        blk = DoubleConv3d(ci, co, precision='bf16')
+        g = torch.Generator(device='cpu').manual_seed(ci)
+        blk.load({'conv.0.weight': 0.05 * torch.randn(co, ci, 3, 3, 3, generator=g), 'conv.3.weight': 0.05 * torch.randn(co, co, 3, 3, 3, generator=g)})
+        cp = (ci + 15) // 16 * 16
+        x = torch.zeros(N, D, S, S, cp, dtype=torch.bfloat16, device=dev)
+        x[..., :ci] = torch.randn(N, D, S, S, ci, generator=g).to(dev).to(torch.bfloat16)
+        dy = torch.randn(N, D, S, S, co, generator=g).to(dev).to(torch.bfloat16)
+
+        def fb():
+            blk.forward(x)
+            blk.backward(dy)
+        fb(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fb()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        vox = N * D * S * S
+        # conv.0: fwd + wgrad (+ dgrad when the padded input is >= 64 channels); conv.3: fwd + dgrad + wgrad
+        fl = 2.0 * vox * 27 * (co * ci * (3 if cp % 64 == 0 else 2) + co * co * 3)
+        out[f'{ci}->{co}'] = {'ms_fwd_bwd': ms, 'GFLOP': fl / 1e9, 'TFLOPs': fl / ms / 1e9, 'frac_of_mfma_peak': fl / ms / 1e9 / (MFMA_BF16_PEAK / 1e12),
+                              'samples_per_s': N / ms * 1e3}
+    return out
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -596,7 +726,12 @@ def main():
         for name, flops, e0, e1 in raw:
             a = conv_all.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
-        eng.prof_filter = max(conv_all.items(), key=lambda kv: kv[1][2])[0]
+        fam_all = {}
+        for name, v in conv_all.items():
+            a = fam_all.setdefault(family_of(name), [0, 0.0, 0.0, []])
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3].append(name)
+        dom_family = max(fam_all.items(), key=lambda kv: kv[1][2])[0]
+        eng.prof_filter = tuple(fam_all[dom_family][3])          # every instantiation of the family with the most time per step
     classes = None
     if not args.no_roofline and rank == 0:
         try:
@@ -608,7 +743,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    n_dom = conv_all[eng.prof_filter][0] if not args.no_roofline else 0
+    n_dom = fam_all[dom_family][0] if not args.no_roofline else 0
     if not args.no_roofline:
         eng.prof = []
     picks = []
@@ -645,7 +780,9 @@ def main():
 
     roofline = None
     if prof:
-        name = eng.prof_filter
+        name = dom_family
+        members = list(eng.prof_filter)
+        per_step_launches = {m: conv_all[m][0] for m in members}
         # one sample per step, launch shapes round robin; every SHAPE gets the same weight whatever K mod n is:
         # achieved = sum over shapes of its FLOP / sum over shapes of its mean duration
         per = {}
@@ -657,13 +794,24 @@ def main():
         peak = MFMA_F32_PEAK if args.precision == 'fp32' else MFMA_BF16_PEAK
         achieved = flop_sum / time_sum
         conv_total = sum(v[2] for v in conv_all.values())
-        tr = pmc_traffic(name, args.precision)
-        ravg, rsrc = rocprof_avg_us(name, args.precision)
-        roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved / 1e12, 'peak': peak / 1e12,
+        tr = pmc_family_traffic(members, per_step_launches, args.precision)
+        ravg, rsrc = rocprof_family_avg_us(members, args.precision)
+        step_s = ms_step * 1e-3
+        families = {}
+        for fam, (nl, fl, sec, names) in sorted(fam_all.items(), key=lambda kv: -kv[1][2]):
+            fr, _ = rocprof_family_avg_us(names, args.precision)
+            families[fam] = {'launches_per_step': nl, 'ms_per_step': round(sec * 1e3, 4), 'TFLOPs': fl / sec / 1e12, 'frac': fl / sec / peak,
+                             'GFLOP_per_step': fl / 1e9, 'instantiations': sorted(names), 'rocprof_avg_launch_us': fr}
+        roofline = {'bound': 'mfma', 'kernel': name, 'kernel_instantiations': sorted(members),
+                    'achieved': achieved / 1e12, 'peak': peak / 1e12,
                     'unit': 'TFLOP/s', 'frac': achieved / peak,
                     'traffic': None if tr is None else tr['hbm_read'] + tr['hbm_write'], 'traffic_detail': tr,
                     'launches_per_step': n_dom, 'sampled_launches': len(prof), 'shapes_sampled': len(per),
-                    'sampling': 'one launch per timed step, round robin over the launches of a step; shapes weighted equally',
+                    'sampling': 'one launch of the family per timed step, round robin over its launches of a step; launches weighted equally',
+                    'families': families,
+                    'families_how': 'kernel FAMILY = all instantiations of one template (conv3x3_kernel<*>: forward + data gradient; wgrad7_kernel<*>: '
+                                    'weight-gradient GEMM with / without BatchNorm+ReLU on load); `kernel` is the family with the most summed time in '
+                                    'one fully instrumented untimed step, `families` lists every family with its ms / TFLOP/s / fraction of peak there',
                     'avg_launch_us': time_sum / len(per) * 1e6, 'rocprof_avg_launch_us': ravg, 'rocprof_source': rsrc,
                     'flop_per_launch': flop_sum / len(per),
                     'all_mfma_kernels': {'source': 'one fully instrumented untimed step (conv3x3 fwd/dgrad + weight-gradient GEMMs)',
@@ -671,6 +819,8 @@ def main():
                                          'seconds_per_step': conv_total,
                                          'achieved': sum(v[1] for v in conv_all.values()) / conv_total / 1e12}}
         if name.startswith('wgrad') and name != 'wgrad_first_kernel':
+            roofline['note'] = ('the weight-gradient GEMMs run on the second stream CONCURRENTLY with the dz chain on a half-chip grid: the in-step '
+                                'launch duration (and so `frac`) is what the GEMM gets beside the chain, not its stand-alone rate')
             # the weight-gradient GEMMs run on the second stream beside the dz chain, on a grid of HALF the CUs by design
             # (fabric_amd/csrc/wgrad.hip wgrad_plan; engine.wgrad_blocks overrides): `frac` above is against the FULL-chip peak
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -720,6 +870,12 @@ def main():
             del ts, model, eng, x1, x2, lbl
             torch.cuda.empty_cache()
             out['parity_setting'] = parity_leg(dev, B, C, S)
+            for key, leg in (('val_f1', val_f1_leg), ('conv3d', conv3d_leg)):
+                try:
+                    out[key] = leg(dev)
+                except Exception as e:                            # a bench line without a side leg beats no bench line
+                    out[key] = {'error': f'{type(e).__name__}: {e}'}
+                torch.cuda.empty_cache()
             out['scene'] = scene_leg(dev, size=args.scene_size)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -55,6 +55,7 @@ SIGNATURES = {
     'bdn_bnrelu_pool': (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_fuse_product': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_product_pool': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_product_pool_dates': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_product_pool_split': (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_upsample2x_split': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -114,10 +114,7 @@ template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, b
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 // the multi-chunk 64-wide instantiation on 8 x 16 tiles needs 171 registers: at three blocks per CU (168) it spilled three of them;
 // two blocks per CU measure the same (d1a fwd 74.6 -> 73.8 us, step 6.16 ms either way) without scratch
-#ifndef CONV_N64_BLOCKS
-#define CONV_N64_BLOCKS 2
-#endif
-__global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8) ? CONV_N64_BLOCKS : 3) : 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8) ? 2 : 3) : 2) void conv3x3_kernel(ConvArgs a) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
@@ -552,13 +549,7 @@ static ConvPlan conv_plan(int N, int H, int W, int Cout, int imgs_per_group) {
     TileGeom& g = p.g;
     const bool narrow = (Cout % 128 != 0);
     if (W <= 8 && H <= 8 && imgs_per_group % 2 == 0) { g.TI = 2; g.TH = 8; g.TW = 8; }
-#ifndef NO_T16
     else if (narrow && H >= 12 && W >= 12) { g.TI = 1; g.TH = 16; g.TW = 16; }
-#endif
-#ifdef WIDE_T16
-    else if (!narrow && H >= 16 && W >= 16 &&
-             (long)N * ((H + 15) / 16) * ((W + 15) / 16) * (Cout / 128) >= WIDE_T16) { g.TI = 1; g.TH = 16; g.TW = 16; }
-#endif
     else { g.TI = 1; g.TH = 8; g.TW = 16; }
     g.tiles_y = (H + g.TH - 1) / g.TH;
     g.tiles_x = (W + g.TW - 1) / g.TW;
@@ -571,9 +562,6 @@ static ConvPlan conv_plan(int N, int H, int W, int Cout, int imgs_per_group) {
 template <typename T, int CKB>
 static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
-#ifdef WIDE_T16
-    if (g.TH == 16 && p.BN == 128) return launch_conv<T, CKB, 16, 16, 1, 128, 2, 2>(a, g.n_mtiles, st);
-#endif
     const bool one = (a.C0 + a.C1) * (int)sizeof(T) == CKB;
     // 64-wide outputs on 16x16 tiles: the single-chunk kernels (three blocks per CU share one L1) take the 2x2 wave
     // layout, whose waves stream half the filter bytes each (e1b: +9..12 %); with several chunks the 4x1 layout wins

@@ -156,7 +156,7 @@ extern "C" int bdn_fuse_product(int dtype, const void* z, const float* bn, void*
 // iteration = one 2x2 window x EPU channels x both dates, so z is read from HBM once instead of twice.
 template <typename T>
 __global__ void product_pool_kernel(const T* __restrict__ z, const float* __restrict__ bn, T* __restrict__ f, T* __restrict__ pool,
-                                    int B, int H, int W, int C, int ncell, SplitOut sf, SplitOut sp, FastDiv dWc, FastDiv dHc) {
+                                    int B, int H, int W, int C, int ncell, SplitOut sf, SplitOut sp, FastDiv dWc, FastDiv dHc, int pool_dates) {
     constexpr int EPU = ET<T>::EPU;
     const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
@@ -189,21 +189,21 @@ __global__ void product_pool_kernel(const T* __restrict__ z, const float* __rest
         }
         if (yc < Ho && xc < Wo) {                                           // floor-mode pooling drops a trailing odd row / column
             const size_t q0 = (size_t)(b * Ho + yc) * Wo + xc, q1 = (size_t)((B + b) * Ho + yc) * Wo + xc;
-            store_out<T>(pool, q0 * C + c, sp, q0, c, m0);
-            store_out<T>(pool, q1 * C + c, sp, q1, c, m1);
+            if (pool_dates & 1) store_out<T>(pool, q0 * C + c, sp, q0, c, m0);      // pool_dates: which dates' pooled maps this launch writes
+            if (pool_dates & 2) store_out<T>(pool, q1 * C + c, sp, q1, c, m1);
         }
     }
 }
 
 static int product_pool_impl(int dtype, const void* z, const float* bn, void* f, void* pool, SplitOut sf, SplitOut sp,
-                             int B, int H, int W, int C, void* stream) {
+                             int B, int H, int W, int C, void* stream, int pool_dates = 3) {
     if (C % 16 || C > 1024 || 1024 % C || H < 2 || W < 2) BDN_FAIL(BDN_E_SHAPE, "product_pool: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int ncell = B * ((H + 1) / 2) * ((W + 1) / 2);
     if (dtype == BDN_BF16) { const int per = 256 / (C / 8) * 4;
-        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell, sf, sp, FastDiv((W + 1) / 2), FastDiv((H + 1) / 2)); }
+        hipLaunchKernelGGL(product_pool_kernel<bf16s>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const bf16s*)z, bn, (bf16s*)f, (bf16s*)pool, B, H, W, C, ncell, sf, sp, FastDiv((W + 1) / 2), FastDiv((H + 1) / 2), pool_dates); }
     else if (dtype == BDN_F32) { const int per = 256 / (C / 4) * 4;
-        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell, sf, sp, FastDiv((W + 1) / 2), FastDiv((H + 1) / 2)); }
+        hipLaunchKernelGGL(product_pool_kernel<float>, dim3((ncell + per - 1) / per), dim3(256), 0, st, (const float*)z, bn, (float*)f, (float*)pool, B, H, W, C, ncell, sf, sp, FastDiv((W + 1) / 2), FastDiv((H + 1) / 2), pool_dates); }
     else BDN_FAIL(BDN_E_ARG, "product_pool: bad dtype");
     BDN_CHECK_LAUNCH("product_pool");
     return BDN_OK;
@@ -214,6 +214,14 @@ extern "C" int bdn_product_pool(int dtype, const void* z, const float* bn, void*
     if (!z || !bn || !f || !pool) BDN_FAIL(BDN_E_ARG, "product_pool: null pointer");
     const SplitOut none = {nullptr, 0, 0, 0};
     return product_pool_impl(dtype, z, bn, f, pool, none, none, B, H, W, C, stream);
+}
+
+extern "C" int bdn_product_pool_dates(int dtype, const void* z, const float* bn, void* f, void* pool, int pool_dates,
+                                      int B, int H, int W, int C, void* stream) {
+    if (!z || !bn || !f || !pool) BDN_FAIL(BDN_E_ARG, "product_pool_dates: null pointer");
+    if (pool_dates < 0 || pool_dates > 3) BDN_FAIL(BDN_E_ARG, "product_pool_dates: pool_dates must be a mask of bits 0 (date 1) and 1 (date 2)");
+    const SplitOut none = {nullptr, 0, 0, 0};
+    return product_pool_impl(dtype, z, bn, f, pool, none, none, B, H, W, C, stream, pool_dates);
 }
 
 // bf16x3 setting: both outputs leave as the [hi | lo] bf16 operands of the convolutions that consume them -- f into channels [0, C) of the
@@ -553,11 +561,7 @@ static int upsample2x_bwd_impl(int dtype, const void* dU, int ldU, void* dsrc, c
     const int epu = dtype == BDN_BF16 ? 8 : 4;
     if (ups_bwd_tiled_ok(dtype, h, w, C)) {
         const int tx = (w + 7) / 8, ty = (h + 7) / 8;
-#ifdef UPS_BWD_UB4
-        const bool wide = false;                                   // timing-only build: the round-3 block shape
-#else
         const bool wide = C % (8 * epu) == 0;                      // whole 128-byte (bf16) channel rows per pixel
-#endif
         const dim3 grid(tx * ty * B, C / ((wide ? 8 : 4) * epu));
 #define UPS_BWD_LAUNCH(T_, UB_) hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<T_, UB_>), grid, dim3(64 * UB_), 0, st, (const T_*)dU, ldU, (T_*)dsrc, h, w, H, W, C, \
                                                    tx, ty, sy, sx, (const T_*)z_prev, bn_prev, bs_partial)
@@ -595,11 +599,8 @@ extern "C" int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* d
 // sum g*z with g = dA * [relu(bn(z)) > 0], on the STORED, rounded dA), so no separate reduction pass reads dA and z.
 // The two-pass variant that never writes dA (sums pass + fused apply pass, 22 % fewer bytes) measured +1.9 % step time in
 // round 2 -- its argmax / product work runs twice -- and lives in tools/experimental/enc_skip_two_pass.hip.inc.
-#ifndef ENC_SKIP_BLOCKS
-#define ENC_SKIP_BLOCKS 1
-#endif
 template <typename T, int EPU>
-__global__ __launch_bounds__(256, ENC_SKIP_BLOCKS) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
+__global__ __launch_bounds__(256, 1) void enc_skip_bwd_kernel(const T* __restrict__ dF, int ldF, const T* __restrict__ z, const float* __restrict__ bn,
                                     const T* __restrict__ dP, T* __restrict__ dA, float* __restrict__ bs_partial,
                                     int B, int H, int W, int C, int ncell, int IT, FastDiv dWc, FastDiv dHc) {
     using U = UnitE<T, EPU>;

@@ -10,7 +10,7 @@
 // Per chunk the dz tile [128 px][64 co] and the activation halo patch [(8+2)x(16+2) px][64 ci]
 // are staged into LDS in their natural NHWC order; the MFMA operands need 8 consecutive *pixels*
 // per lane, which on gfx950 is exactly what ds_read_b64_tr_b16 delivers from a channel-minor
-// image (lane-group semantics pinned by tools/probe_hw.hip): no transposed copy ever exists.
+// image (lane-group semantics pinned by tools/archive/probe_hw.hip): no transposed copy ever exists.
 // The f32 variant feeds v_mfma_f32_32x32x2_f32, whose one-value-per-lane operands are plain
 // conflict-free ds_read_b32.
 #include "common.hpp"
@@ -157,9 +157,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 || KSPLIT) ? 1 : 2) void wgrad
         STORE_CHUNK()
         __syncthreads();
         if (q + 1 < q_end) LOAD_CHUNK(q + 1)
-#ifndef WG_NOSCHED
         __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads above the MFMAs (the scheduler sinks them otherwise)
-#endif
 
         if constexpr (sizeof(T) == 2) {
             // lane's transposing-read role: pixel (lane&15)>>2 of a 4-pixel group, 4-channel piece (lane&3)
@@ -234,7 +232,7 @@ struct Wg6 {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 // one LDS-DMA piece: every lane's 16 bytes at (descriptor base + voff) -> LDS byte (lds_dst + 16 lane); a lane whose offset lies
-// beyond the descriptor's num_records reads 0, and the DMA writes that 0 (tools/probe_dma.hip) -- zero padding, ragged tiles and
+// beyond the descriptor's num_records reads 0, and the DMA writes that 0 (tools/archive/probe_dma.hip) -- zero padding, ragged tiles and
 // chunks past a split's end cost no instruction.  Inline asm on purpose: hipcc's wait-count pass drains the VM queue (vmcnt(0))
 // before the next LDS access behind an LDS-DMA it can see, which serialises the pipeline; this one is invisible to it and is
 // waited for by hand.  M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
@@ -254,7 +252,7 @@ __device__ __forceinline__ u32x4_t raw_rsrc(const void* base, unsigned num_recor
 // x all nine taps (9 accumulators per MFMA wave), a contiguous range of 128-pixel chunks per block, three LDS chunk buffers (120 KB),
 // ONE barrier per chunk.  The MFMAs walk the patch ROW by ROW: the three fragments of patch row pr feed tile rows pr, pr-1, pr-2 (taps
 // r = 0, 1, 2), so every patch fragment is read from LDS once (30 fragment reads per chunk instead of 72) and the reads of row pr+1
-// are issued ahead of the MFMAs of row pr (ds_read_b64_tr_b16: lane-group semantics pinned by tools/probe_hw.hip).
+// are issued ahead of the MFMAs of row pr (ds_read_b64_tr_b16: lane-group semantics pinned by tools/archive/probe_hw.hip).
 // The block is split by ROLE -- made for the half-chip grid, where a weight-gradient block owns its CU anyway (the retired four-wave
 // kernels wgrad2 / wgrad6, tools/experimental/wgrad_v2_v6.hip.inc, compute the same values bit for bit):
 //   waves 0-3  CONSUMERS, one per SIMD: 76 transposing fragment reads + 72 MFMAs per chunk and nothing else;
@@ -759,9 +757,7 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 //   flags bits 0-1   phases (bdn_conv3x3_wgrad_ex)
 //   flags bits 8-11  kernel override: 0 = the library's choice, BDN_WG_SIMPLE forces the one-chunk-at-a-time kernel
 //   flags bits 16-28 target grid size of the GEMM (0 = default, one block per CU)
-#ifndef WG_SIMPLE_MULT
-#define WG_SIMPLE_MULT 2
-#endif
+constexpr int WG_SIMPLE_MULT = 2;
 constexpr int WG_X3_SKIP = 1 << 30;          // internal plan flag, see wgrad_plan
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; int variant; int x3h, n_tiles; };
 static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {

@@ -25,7 +25,7 @@ ENC_CH = (64, 128, 256, 512, 512)           # models/bidate_model.py:10-14
 DEC_OUT = (256, 128, 64, 64)                # models/bidate_model.py:16-19
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-FUSE_UPS_BS = 1          # tools/ab_attr.py switch: upsample2x_bwd leaves the BatchNorm-backward partial sums (0: separate reduction pass)
+FUSE_UPS_BS = 1          # tools/archive/ab_attr.py switch: upsample2x_bwd leaves the BatchNorm-backward partial sums (0: separate reduction pass)
 
 
 def _round_up(v, m):
@@ -80,6 +80,19 @@ def param_order(n_channels):
     return order
 
 
+class _LazyBufs(dict):
+    """key -> tensor, allocated on first access.  The skips f_k, pooled maps and upsampled maps are not touched by a bf16x3 TRAINING
+    forward (their producers store split GEMM operands instead), so a workspace that only ever trains in that setting never pays for them."""
+
+    def __init__(self, shapes, alloc):
+        super().__init__()
+        self._shapes, self._alloc = shapes, alloc
+
+    def __missing__(self, key):
+        t = self[key] = self._alloc(*self._shapes[key])
+        return t
+
+
 class Workspace:
     """All device buffers for one (B, H, W) problem shape."""
 
@@ -96,7 +109,8 @@ class Workspace:
         e = lambda *s: torch.empty(*s, dtype=td, device=device)
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         self.x0 = e(2 * B, H, W, eng.cp)
-        self.z, self.bn, self.pool, self.f, self.U = {}, {}, {}, {}, {}
+        self.z, self.bn = {}, {}
+        pool_s, f_s, U_s = {}, {}, {}
         for L in eng.layers:
             hk, wk = self.dims[L.level - 1]
             n = 2 * B if L.enc else B
@@ -105,13 +119,18 @@ class Workspace:
         for k in range(1, 6):
             hk, wk = self.dims[k - 1]
             if k >= 2:
-                self.pool[k] = e(2 * B, hk, wk, ENC_CH[k - 2])
-            self.f[k] = e(B, hk, wk, ENC_CH[k - 1])
+                pool_s[k] = (2 * B, hk, wk, ENC_CH[k - 2])
+            f_s[k] = (B, hk, wk, ENC_CH[k - 1])
         cprev = ENC_CH[4]
         for j in range(1, 5):
             hk, wk = self.dims[4 - j]
-            self.U[j] = e(B, hk, wk, cprev)
+            U_s[j] = (B, hk, wk, cprev)
             cprev = DEC_OUT[j - 1]
+        self.pool, self.f, self.U = _LazyBufs(pool_s, e), _LazyBufs(f_s, e), _LazyBufs(U_s, e)
+        if not eng.x3:                                    # every other setting uses all of them in every forward: allocate now, in one place
+            for d_ in (self.pool, self.f, self.U):
+                for key in d_._shapes:
+                    d_[key]
         lib = _lib.load()
         n_stats = n_bnb = n_wg = 1
         for L in eng.layers:
@@ -205,18 +224,19 @@ class BiDateEngine:
         self._packed_valid = False
         self._pack_desc = None
         self._packed_versions = None
-        # The only tuning attributes (tools/ab_flag.py A/Bs them in one process).  Everything round 1 and 2 measured and lost -- the
+        # The only tuning attributes (tools/archive/ab_flag.py A/Bs them in one process).  Everything round 1 and 2 measured and lost -- the
         # unfused BatchNorm-backward paths, relu(bn(z)) materialised for the weight gradient, the two-pass encoder skip backward,
         # release schedules of the weight-gradient GEMMs -- is gone from the product (DESIGN.md section 4 keeps the findings,
         # tools/experimental/ the code).
         # layers (64 output channels) whose BatchNorm backward is applied inside their data-gradient conv (bdn_conv3x3_dgrad_bb) instead of by the
-        # bn_bwd_apply pass.  In-process A/B (tools/ab_fold.py): e1b -0.6 % step time, d4a +0.4 %, d3a+d3b +0.5 % -- only e1b is folded
+        # bn_bwd_apply pass.  In-process A/B (tools/archive/ab_fold.py): e1b -0.6 % step time, d4a +0.4 %, d3a+d3b +0.5 % -- only e1b is folded
         self.fold_bn_bwd = ('e1b',)
-        # forward schedule (tools/ab_flag.py).  fwd_chains = 2: the two dates go through encoder levels 1..fwd_chain_levels as two B-image chains on
+        # forward schedule (tools/archive/ab_flag.py).  fwd_chains = 2: the two dates go through encoder levels 1..fwd_chain_levels as two B-image chains on
         # two streams (the BatchNorm groups are per date already, so tables and bits do not change): one date's convolutions cover the
         # other's statistics reductions / finalizes / pooling; the chains join where the skip product needs both dates.
         # defer_product = 1: at the split levels each chain pools its own date (bdn_bnrelu_pool) and the skip products f_k run on the
-        # second stream beside encoder levels 4-5 (they are first read by the decoder).
+        # second stream beside encoder levels 4-5 (they are first read by the decoder); 0: products at the join, on the chain stream;
+        # 2: date 0's chain pools its own map, date 1's chain forms skip + its pooled map in one pass (bdn_product_pool_dates).
         self.fwd_chains = 1
         self.fwd_chain_levels = 3
         self.defer_product = 1
@@ -226,9 +246,11 @@ class BiDateEngine:
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
+        self._diag_skip_handoff = 0     # timing diagnostics only (results WRONG): 1 = the weight-gradient GEMMs are released without the event hand-off
+        self._diag_skip_reduce = 0      # timing diagnostics only (results WRONG): 1 = the split-K reductions of the weight-gradient GEMMs are not launched
         self.prof_pick = None      # with prof_filter: index of the one matching launch per step that gets the event pair
         self._prof_seen = 0
-        self.prof_filter = None    # only time launches of this kernel instantiation (an event pair is a ~150 us pipeline bubble)
+        self.prof_filter = None    # tuple of kernel instantiation names: only their launches are timed (an event pair is a ~150 us pipeline bubble)
         self.prof = None           # list collecting (kernel name, algorithmic flops, start event, end event)
         _lib.load()                # fail loudly now if the HIP extension is missing
 
@@ -239,7 +261,7 @@ class BiDateEngine:
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
         name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
-        if self.prof is None or (self.prof_filter is not None and name != self.prof_filter):
+        if self.prof is None or (self.prof_filter is not None and name not in self.prof_filter):
             call(fn, *args)
             return
         if self.prof_pick is not None:              # sparse sampling: bracket only the prof_pick-th matching launch of this step
@@ -272,6 +294,13 @@ class BiDateEngine:
                 return ws
         pool.append(Workspace(self, B, H, W, device))
         return pool[-1]
+
+    def drop_workspaces(self, slot):
+        """Forget every un-leased workspace of `slot` (scene inference's second lane): the tensors go back to the caching allocator."""
+        for key in [k for k in self._ws if k[4] == slot]:
+            self._ws[key] = [w for w in self._ws[key] if w.leased]
+            if not self._ws[key]:
+                del self._ws[key]
 
     def _weights(self, L, P, need_wd):
         """Packed GEMM images of layer L (forward image, data-gradient image).  All 18 layers are (re)packed by
@@ -429,8 +458,8 @@ class BiDateEngine:
         for k in range(k_first, 6):
             hk, wk = ws.dims[k - 1]
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
-            src = ws.x0 if k == 1 else ws.pool[k]           # pool[k] was written together with the skip of level k-1
             pre = self.x3 and training                      # bf16x3 training: pooled maps, skips and upsampled maps are stored as split operands
+            src = ws.x0 if k == 1 else (None if pre else ws.pool[k])   # pool[k] was written together with the skip of level k-1
             za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb, presplit=pre and k > 1)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st, rb)
             if k < 5 and pre:
@@ -459,7 +488,8 @@ class BiDateEngine:
             if deferred is not None and k <= deferred[0]:
                 deferred[1].wait(torch.cuda.current_stream(dev))     # the skip products of the split levels were left on the second stream
                 deferred = None
-            za, bna = self._conv(ws, La, P, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, IN_PLAIN, None, B, B, training, st, rb, presplit=pre)
+            za, bna = self._conv(ws, La, P, None if pre else ws.f[k], ENC_CH[k - 1], None if pre else ws.U[j], cprev, IN_PLAIN, None, B, B,
+                                 training, st, rb, presplit=pre)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st, rb)
             prev, prev_bn, prev_mode, cprev = zb, bnb, IN_BNRELU, Lb.cout
         logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)
@@ -494,6 +524,7 @@ class BiDateEngine:
             ev[0] += 1
             return self._fwd_handoff(dev, ev[0] - 1)
 
+        self._weights(self.layers[0], P, False)              # (re)pack the filter images NOW, on the chain stream, in front of the fork
         start = new_ev()
         start.signal(main)                                   # packed input and packed weights are ready
         start.wait(second)
@@ -513,12 +544,22 @@ class BiDateEngine:
                         return dict(before_finalize=lambda: fin_events[L.name].wait(stream))
                     za, bna = self._conv(ws, La, P, src[d * B:(d + 1) * B], La.cin, None, 0, IN_PLAIN, None, B, B, True, sp, date=d, **order(La))
                     zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, True, sp, date=d, **order(Lb))
-                    if self.defer_product or k < Lmax:
+                    if self.defer_product == 2:
+                        # date 0's chain pools its own map and runs on; date 1's chain forms the skip (it needs date 0's z and table: ordered
+                        # behind date 0's finalize of this layer already) together with ITS pooled map in one pass
+                        if d == 0:
+                            call('bdn_bnrelu_pool', self.dt, ptr(zb), ptr(bnb), B, ptr(ws.pool[k + 1][:B]), B, hk, wk, ENC_CH[k - 1], sp)
+                        else:
+                            call('bdn_product_pool_dates', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[k]), ptr(ws.pool[k + 1]), 2,
+                                 B, hk, wk, ENC_CH[k - 1], sp)
+                    elif self.defer_product or k < Lmax:
                         # each chain pools its own date; the skip product follows off the critical path (or at the join)
                         call('bdn_bnrelu_pool', self.dt, ptr(zb), ptr(bnb), B, ptr(ws.pool[k + 1][d * B:(d + 1) * B]), B, hk, wk, ENC_CH[k - 1], sp)
         join = new_ev()
         join.signal(second)
         join.wait(main)
+        if self.defer_product == 2:
+            return Lmax + 1, None
         # ---- skip products of the split levels: need both dates
         def products(sp, levels):
             for k in levels:
@@ -631,14 +672,14 @@ class BiDateEngine:
                     small = wk <= 8 and hk <= 8 and ipg % 2 == 0
                     name = (f'wgrad_kernel<{"bf16" if self.precision == "bf16" else "f32"},8,{"8,2" if small else "16,1"},'
                             f'{"true" if c0 + c1 <= 32 else "false"}>')
-                if self.prof_filter is not None and name != self.prof_filter:
+                if self.prof_filter is not None and name not in self.prof_filter:
                     name = None
                 elif self.prof_pick is not None:
                     self._prof_seen += 1
                     if self._prof_seen - 1 != self.prof_pick:
                         name = None
             if name is None:
-                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(3, wk_, blk_), stp)
+                call('bdn_conv3x3_wgrad_ex', *args, wg_flags(1 if self._diag_skip_reduce else 3, wk_, blk_), stp)
                 return
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -659,6 +700,8 @@ class BiDateEngine:
                     pool.append(HandOff())
             ho = pool[n_hand[0]]
             n_hand[0] += 1
+            if self._diag_skip_handoff:
+                return
             ho.signal(src)
             ho.wait(dst)
 
@@ -749,7 +792,8 @@ class BiDateEngine:
                 wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             else:
                 dza = bn_bwd(La, ptr(dAa), La.cout, B, B, fused_rows=rows)
-                wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
+                # bf16x3: the operand is the split buffer the forward left (('a', layer)); the float32 skip / upsampled map do not exist
+                wgrad(La, dza, None if self.x3 else ws.f[k], ck, None if self.x3 else ws.U[j], cprev, IN_PLAIN, None, B, B)
                 dc = dgrad(La, dza, B, B)                   # [B,hk,wk, ck + cprev] = [dF_k | dU_j]
             dcat[k] = dc
             dprev = e(B, hs, wsrc, cprev)
@@ -796,7 +840,7 @@ class BiDateEngine:
                 wargs = (self.dt, ptr(dAa), La.cout, ptr(ws.z[La.name]), ptr(ws.bn[La.name]), ptr(sc['sums']), B, La.cout,
                          ptr(ws.x0), La.cin, ptr(sc['wg1']), ptr(grads[f'{La.conv}.weight']), La.cin_real, 2 * B, hk, wk, st)
                 if not self._diag_skip_wgrad:
-                    if self.prof is not None and self.prof_filter in (None, 'wgrad_first_kernel'):
+                    if self.prof is not None and (self.prof_filter is None or 'wgrad_first_kernel' in self.prof_filter):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                         call('bdn_conv3x3_wgrad_bnbwd', *wargs)
@@ -815,7 +859,7 @@ class BiDateEngine:
                 keep += [dAb, dzb, dAa, dP]
                 dP = None
                 continue
-            src = ws.x0 if k == 1 else ws.pool[k]
+            src = ws.x0 if k == 1 else (None if self.x3 else ws.pool[k])
             if La.name in fold and k > 1 and min(hk, wk) > 8 and La.cout == 64:
                 dza, dP_new = fold_dgrad(La, ptr(dAa), 2 * B, B, rows)
                 wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)

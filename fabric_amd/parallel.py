@@ -27,10 +27,12 @@ def init_rccl(rank, world_size, device, high_priority=False):
 
     The collectives' internal stream keeps the DEFAULT priority.  A high-priority collective stream looks attractive (a bucket
     all-reduce is small and on the path to the optimizer step) but measured, with one rank and forced buckets, +48...+59 % step
-    time when the group is created after the step's streams (+1 % when created first, +0.4-1 % with GPU_MAX_HW_QUEUES=8 -- while
-    the DEFAULT priority with 8 queues cost +8...+16 %).  The mechanism is not established (a sleep-kernel probe does not find the
-    collective stream on the chain's hardware queue); default priority with the default queue count is the one configuration that
-    measured +1.0-1.2 % in both creation orders, and bench.py reports the overhead it sees (`collectives`)."""
+    time when the group is created after the step's streams (+1 % when created first).  Mechanism (round 4):
+    HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues per priority class in creation order, and in that arrangement
+    RCCL's collective stream lands on the hardware queue of the step's high-priority chain stream, so every bucket all-reduce
+    serialises with the dz chain; a NEW chain stream (created after the group) removes it (+0.6 %).  The library cannot see RCCL's
+    stream, so TrainStep.guard_collectives MEASURES the overhead on the real arrangement before a loop starts and re-creates the
+    step's streams when it is the slow one; bench.py reports what it saw (`collectives`)."""
     import os
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # the host driver only supports dmabuf IPC

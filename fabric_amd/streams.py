@@ -43,8 +43,11 @@ def get(role, device=None):
         return s
 
 
-_graveyard = []          # streams that collided with another role's hardware queue: kept alive so that their queue slot stays taken
-_GRAVEYARD_CAP = 16      # parked streams per process; beyond that the oldest is destroyed (its slot is long since behind newer streams)
+_graveyard = []          # NEVER-USED streams that collided with another role's hardware queue while a role stream was being created:
+                         # kept alive so that their queue slot stays taken
+_GRAVEYARD_CAP = 16      # such streams per process; beyond that the oldest is destroyed (nothing ever ran on it but the probe)
+_retired = []            # former ROLE streams (replace()): work, events and a caller's `torch.cuda.stream(...)` scope may still refer to
+                         # them, so they are never destroyed before the process exits
 
 
 def _park(s):
@@ -65,6 +68,8 @@ def _bury_all():
     """atexit: parked streams are destroyed (the role streams in use stay with the process until the HIP runtime tears down)."""
     while _graveyard:
         _destroy(_graveyard.pop())
+    while _retired:
+        _destroy(_retired.pop())
 
 
 import atexit
@@ -85,7 +90,7 @@ def _create(idx, role):
 
 def _create_distinct(idx, role, tries=6):
     """A new stream for `role` that shares its hardware queue with none of the device's other role streams.  HIP multiplexes streams
-    onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority class in creation order (tools/probe_queues.py: the 5th and 6th
+    onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority class in creation order (tools/archive/probe_queues.py: the 5th and 6th
     normal-priority streams of a process land on the queues of the 3rd and 4th), so a stream created late may be serialised with the
     chain or the weight-gradient stream.  Checked with `serialised` against the library's OTHER role streams of the device and torch's
     default stream; a colliding stream is parked (it keeps its slot) and another one is created.  Streams the library cannot see -- a
@@ -106,17 +111,35 @@ def _create_distinct(idx, role, tries=6):
 
 
 def replace(role, device=None):
-    """Park the current stream of `role` and create a new one (TrainStep.guard_collectives: the role's stream turned out to be slowed
+    """Retire the current stream of `role` and create a new one (TrainStep.guard_collectives: the role's stream turned out to be slowed
     down by a stream the library does not own, e.g. RCCL's collective stream).  Nothing in the library caches a role stream across
-    calls (engines, TrainStep.stream() and the feeders fetch it on every use); work already queued on the parked stream completes."""
+    calls (engines, TrainStep.stream() and the feeders fetch it on every use); work already queued on the retired stream completes, and
+    the stream object stays valid for whoever still holds it (it is only destroyed at process exit)."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     with _lock:
         old = _streams.pop((idx, role), None)
         if old is not None:
-            _park(old)
+            _retired.append(old)                      # stays alive: the caller may still be inside `with torch.cuda.stream(old)`
         s = _streams[(idx, role)] = _create_distinct(idx, role)
         return s
+
+
+def restore(role, stream, device=None):
+    """Make `stream` -- a former stream of `role`, as returned by get() before a replace() -- the role's stream again (the guard
+    reverts to the arrangement that measured best).  The stream it displaces is retired, never destroyed."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _lock:
+        cur = _streams.get((idx, role))
+        if cur is not None and cur.cuda_stream == stream.cuda_stream:
+            return cur
+        if cur is not None:
+            _retired.append(cur)
+        if stream in _retired:
+            _retired.remove(stream)
+        _streams[(idx, role)] = stream
+        return stream
 
 
 def serialised(a, b, sleep_cycles=6_000_000):

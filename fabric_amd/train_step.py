@@ -21,9 +21,9 @@ from .parallel import FlatLayout, GradBucketer
 class TrainStep:
     def __init__(self, model, lr=1e-3, tversky_alpha=0.1, tversky_beta=0.9, eps=1e-7,
                  process_group=None, n_buckets=4, distributed=True, force_collectives=False, guard=True):
-        """guard: when the step issues collectives (world > 1, or force_collectives), the first step() first runs
-        guard_collectives() -- a few timed steps with and without the bucket all-reduces -- and repairs / reports a stream
-        arrangement in which they slow the step down (see there)."""
+        """guard: when the step issues collectives (world > 1, or force_collectives) and guard_collectives() has not been called, the
+        first step() runs it in its measure-only form (replace_streams=False: it may defer the buckets, it never swaps a stream the
+        caller may already have adopted) and reports / warns about a stream arrangement in which they slow the step down."""
         self.model, self.lr = model, lr
         self._guard = guard
         self.collectives_report = None
@@ -67,10 +67,11 @@ class TrainStep:
 
         The step's dependency chain (forward, loss, dz chain, SGD) is enqueued on a HIGH-priority HIP stream; the
         weight-gradient GEMMs run beside it on a normal-priority stream (engine.backward), so the chain's kernels get
-        compute units first (A/B tools/ab_prio.py: -0.8 % step time).  The caller's current stream is joined on both
+        compute units first (A/B tools/archive/ab_prio.py: -0.8 % step time).  The caller's current stream is joined on both
         sides, so the usual stream semantics hold for inputs and outputs."""
         if self._guard and self.collectives_report is None and self.bucketer.active():
-            self.guard_collectives(*[int(v) for v in (x_d1.shape[0], x_d1.shape[2], x_d1.shape[3])])
+            # measure only: the caller may already run its loop on step.stream(), which must not be swapped under it
+            self.guard_collectives(*[int(v) for v in (x_d1.shape[0], x_d1.shape[2], x_d1.shape[3])], replace_streams=False)
         if not self.high_priority_chain:
             return self._step(x_d1, x_d2, labels)
         cur = torch.cuda.current_stream(x_d1.device)
@@ -108,19 +109,28 @@ class TrainStep:
             torch.cuda.synchronize(dev)
             return (time.perf_counter() - t0) / n
 
-    def guard_collectives(self, B, H, W, steps=8, threshold=0.05, verbose=False):
+    def guard_collectives(self, B, H, W, steps=8, threshold=0.05, verbose=False, replace_streams=True):
         """Is the step slowed down by WHERE its collectives run?  RCCL's collective stream is created by torch, not by this library,
         and its hardware-queue placement relative to the chain / weight-gradient streams depends on creation order, priority and
-        GPU_MAX_HW_QUEUES: one combination measured +48...+59 % step time (DESIGN.md section 5), invisible to a sleep-kernel probe.
-        So it is MEASURED: `steps` steps on synthetic inputs of the run's shape with the bucket all-reduces and without; while the
-        overhead exceeds `threshold` the remedies are tried in order and kept only if they help --
-          1. a new weight-gradient stream (streams.replace: the old one is parked so that its queue slot stays taken),
-          2. a new chain stream,
-          3. the buckets launched from the CHAIN's stream at the end of backward (bucketer.defer: no overlap with backward any more,
-             but no interference either -- costs the exposed transfer instead of half a step);
-        and a RuntimeWarning says so when none of them brings it under the threshold.  With several ranks the decision is taken on the
-        MAX over ranks, so every rank walks the same path.  Parameters, BatchNorm buffers and the bucketer state are restored:
-        the model is exactly as before.  Returns (and keeps in `collectives_report`) what was measured."""
+        GPU_MAX_HW_QUEUES: one combination measured +48...+59 % step time (DESIGN.md section 6), invisible to a sleep-kernel probe.
+        So it is MEASURED, on synthetic inputs of the run's shape, `steps` steps each:
+
+          local      the step without its collectives,
+          overlap    the bucket all-reduces launched from backward (the intended arrangement),
+          deferred   (only if overlap costs more than `threshold`) every bucket launched from the chain's stream after backward: nothing
+                     overlaps, so nothing can interfere -- the reference for what the exchange costs when it is fully exposed.
+
+        overlap <= deferred means the overhead is the exchange itself (xGMI transfer, RCCL's kernels): the arrangement is fine, nothing
+        is changed and nothing is warned about, however large it is.  overlap > deferred means overlapping HURTS, i.e. a placement
+        problem, and the remedies are tried in order -- (1) a new weight-gradient stream, (2) a new chain stream, each measured in the
+        overlap arrangement.  Afterwards the arrangement that measured BEST (original streams, after remedy 1, after remedy 2, or
+        deferred buckets on the best of those) is restored -- streams.restore() puts a displaced stream back -- and the report's
+        `overhead_frac` is the number measured on exactly that arrangement.  With several ranks every decision is taken on the MAX
+        over ranks, so all ranks walk the same path.  Parameters, BatchNorm buffers and the bucketer state are restored.
+
+        replace_streams=False (what the automatic call inside the first step() uses): the stream remedies are skipped -- a caller that
+        already runs its loop on step.stream() must not have that stream swapped under it -- and only deferring is available.
+        Call this method yourself BEFORE `with torch.cuda.stream(step.stream())` to get the full repair (train.py and bench.py do)."""
         import warnings
         from . import streams
         dev = self.flat_params.device
@@ -132,62 +142,91 @@ class TrainStep:
             self.collectives_report = {'active': True, 'guarded': False, 'reason': f'backend {backend}: no device-side collective stream'}
             return self.collectives_report
         self.collectives_report = {'running': True}                     # re-entrancy: _step below must not call the guard again
-        g = torch.Generator(device='cpu').manual_seed(99)
-        C = self.model.n_channels
-        x1 = torch.randn(B, C, H, W, generator=g).to(dev)
-        x2 = (x1 + 0.3 * torch.randn(B, C, H, W, generator=g).to(dev))
-        lbl = (torch.rand(B, H, W, generator=g) < 0.1).to(torch.uint8).to(dev)
-        saved = {k: v.clone() for k, v in self._P.items()}
-        saved_flat = self.flat_params.clone()
+        ok = False
         eng = self.model.engine()
-
-        def overhead():
-            self.bucketer.enabled = False
-            t_local = self._time_steps(x1, x2, lbl, steps, 3)
-            self.bucketer.enabled = True
-            t_coll = self._time_steps(x1, x2, lbl, steps, 3)
-            t = torch.tensor([t_local, t_coll], dtype=torch.float64, device=dev)
-            if self.world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            t_local, t_coll = float(t[0]), float(t[1])
-            return t_coll / t_local - 1.0, t_local, t_coll
-
+        saved = saved_flat = None
         tried = []
         try:
-            ov, tl, tc = overhead()
-            tried.append({'remedy': 'none', 'overhead_frac': ov, 'local_ms': tl * 1e3, 'collectives_ms': tc * 1e3})
-            best = ov
-            for remedy in ('new_wgrad_stream', 'new_chain_stream', 'deferred_buckets'):
-                if best <= threshold:
-                    break
-                if remedy == 'new_wgrad_stream':
-                    streams.replace('wgrad', dev)
-                elif remedy == 'new_chain_stream':
-                    streams.replace('chain', dev)
-                else:
-                    self.bucketer.defer = True
-                ov, tl, tc = overhead()
-                tried.append({'remedy': remedy, 'overhead_frac': ov, 'local_ms': tl * 1e3, 'collectives_ms': tc * 1e3})
-                if remedy == 'deferred_buckets' and ov >= best:
-                    self.bucketer.defer = False                        # did not help: keep the overlapped launches
-                best = min(best, ov)
+            g = torch.Generator(device='cpu').manual_seed(99)
+            C = self.model.n_channels
+            x1 = torch.randn(B, C, H, W, generator=g).to(dev)
+            x2 = (x1 + 0.3 * torch.randn(B, C, H, W, generator=g).to(dev))
+            lbl = (torch.rand(B, H, W, generator=g) < 0.1).to(torch.uint8).to(dev)
+            saved = {k: v.clone() for k, v in self._P.items()}
+            saved_flat = self.flat_params.clone()
+
+            def timed(collectives, defer=False):
+                self.bucketer.enabled, self.bucketer.defer = collectives, defer
+                # inputs and the saved copies were produced on the caller's stream: the chain stream (possibly a new one) joins it first
+                self.stream(dev).wait_stream(torch.cuda.current_stream(dev))
+                t = torch.tensor([self._time_steps(x1, x2, lbl, steps, 3)], dtype=torch.float64, device=dev)
+                if self.world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                return float(t[0])
+
+            def measure(name):
+                t_local = timed(False)
+                t_ov = timed(True)
+                rec = {'arrangement': name, 'local_ms': t_local * 1e3, 'overlap_ms': t_ov * 1e3, 'overhead_frac': t_ov / t_local - 1.0,
+                       'streams': (streams.get('chain', dev), streams.get('wgrad', dev))}
+                tried.append(rec)
                 if verbose:
-                    print(f'guard_collectives: {remedy}: overhead {ov * 100:+.1f} %', flush=True)
+                    print(f'guard_collectives: {name}: overlap overhead {rec["overhead_frac"] * 100:+.1f} %', flush=True)
+                return rec
+
+            first = measure('original')
+            kept, placement = first, None
+            if first['overhead_frac'] > threshold:
+                t_def = timed(True, defer=True)
+                first['deferred_ms'] = t_def * 1e3
+                placement = first['overlap_ms'] > 1.01 * t_def * 1e3          # overlapping is worse than not overlapping
+                if placement and replace_streams:
+                    for remedy in ('new_wgrad_stream', 'new_chain_stream'):
+                        if kept['overhead_frac'] <= threshold:
+                            break
+                        streams.replace('wgrad' if remedy == 'new_wgrad_stream' else 'chain', dev)
+                        rec = measure(remedy)
+                        if rec['overhead_frac'] < kept['overhead_frac']:
+                            kept = rec
+                # back to the best overlap arrangement, then decide between overlap and deferred ON it
+                streams.restore('chain', kept['streams'][0], dev)
+                streams.restore('wgrad', kept['streams'][1], dev)
+                if placement and kept['overhead_frac'] > threshold:
+                    if kept is not first:
+                        t_def = timed(True, defer=True)
+                        kept['deferred_ms'] = t_def * 1e3
+                    if t_def * 1e3 < kept['overlap_ms']:
+                        kept = dict(kept, arrangement=kept['arrangement'] + ' + deferred_buckets', deferred=True,
+                                    overhead_frac=t_def * 1e3 / kept['local_ms'] - 1.0)
+            self.bucketer.defer = bool(kept.get('deferred'))
+            rep = {'active': True, 'threshold': threshold, 'steps': steps, 'world': self.world,
+                   'tried': [{k: v for k, v in r.items() if k != 'streams'} for r in tried],
+                   'kept': kept['arrangement'], 'overhead_frac': kept['overhead_frac'], 'deferred_buckets': bool(kept.get('deferred')),
+                   'placement_problem': placement, 'stream_remedies_allowed': bool(replace_streams),
+                   'recovered': bool(placement) and kept['overhead_frac'] <= threshold,
+                   'ok': kept['overhead_frac'] <= threshold or placement is False}
+            if placement and kept['overhead_frac'] > threshold:
+                hint = ('' if replace_streams else '  The stream remedies were skipped because the guard ran inside step(): call '
+                        'step.guard_collectives(B, H, W) before adopting step.stream().')
+                warnings.warn(f'fabric_amd: launching the gradient all-reduces from backward costs the step {first["overhead_frac"] * 100:+.0f} % '
+                              f'here, more than launching them after it -- a stream-placement problem; kept: {kept["arrangement"]} '
+                              f'({kept["overhead_frac"] * 100:+.0f} %, threshold {threshold * 100:.0f} %).{hint}  Creating the process group BEFORE the '
+                              f'first TrainStep, the default collective-stream priority and the default GPU_MAX_HW_QUEUES avoid it.', RuntimeWarning)
+            ok = True
         finally:
             self.bucketer.enabled = True
+            if not ok:
+                self.bucketer.defer = False
             self.bucketer.reset()
-            for k, v in saved.items():
-                self._P[k].copy_(v)
-            self.flat_params.copy_(saved_flat)
+            torch.cuda.synchronize(dev)                    # chain-stream steps may still be in flight (exception path): restore after them
+            if saved is not None and saved_flat is not None:
+                for k, v in saved.items():
+                    self._P[k].copy_(v)
+                self.flat_params.copy_(saved_flat)
             eng.invalidate_weights()
             torch.cuda.synchronize(dev)
-        rep = {'active': True, 'threshold': threshold, 'steps': steps, 'world': self.world, 'tried': tried,
-               'overhead_frac': tried[-1]['overhead_frac'] if tried else None, 'deferred_buckets': bool(self.bucketer.defer),
-               'recovered': len(tried) > 1 and best <= threshold, 'ok': best <= threshold}
-        if best > threshold:
-            warnings.warn(f'fabric_amd: the gradient all-reduces cost the step {best * 100:+.0f} % (threshold {threshold * 100:.0f} %) and no '
-                          f'stream re-arrangement brought that down: {tried}.  Try creating the process group BEFORE the first TrainStep, the '
-                          f'default (not high) collective-stream priority, and the default GPU_MAX_HW_QUEUES.', RuntimeWarning)
+            if not ok:
+                self.collectives_report = None             # a failed guard has measured nothing: the next call starts over
         self.collectives_report = rep
         return rep
 

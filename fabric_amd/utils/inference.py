@@ -115,7 +115,7 @@ def predict_patches(model, patches1, patches2, batch_size, device='cuda'):
 
 
 @torch.no_grad()
-def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shard=None, merge=True, band_rows=None, two_streams=True):
+def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shard=None, merge=True, band_rows=None, two_streams=None):
     """Change mask of a whole scene.
 
     scene_d1, scene_d2: [C,H,W] float32 tensors (what the reference's city_loader returns per date,
@@ -162,13 +162,29 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
         else torch.empty(h, w, dtype=torch.uint8, device=dev)
     # Tile batches are independent: they alternate between the caller's stream and the library's second stream (idle outside training),
     # each with its own workspace, so that one batch's HBM-bound stages (tile gather, pooling, upsampling, classifier, stitching) run
-    # under the other's convolutions.  two_streams=False: the single-stream loop.
+    # under the other's convolutions (+1.5 %).  The second lane needs a second full workspace (several GB at 256 tiles): it is created
+    # under the CALLER's stream (its blocks belong to the caller's allocator pool) and dropped again on exit, so a training workspace
+    # of the same process can take the memory over.  two_streams=None: only when the device has room for it; False: the single-stream loop.
     from .. import streams as _streams
     cur = torch.cuda.current_stream(dev)
-    lanes = [cur, _streams.get('wgrad', dev)] if two_streams and (hi - lo) > batch_size else [cur]
+    want_two = (hi - lo) > batch_size and two_streams is not False
+    if want_two:
+        nb0 = min(batch_size, hi - lo)
+        a0 = torch.cuda.memory_allocated(dev)
+        eng.workspace(nb0, patch_size, patch_size, dev, 0)
+        first_ws = max(torch.cuda.memory_allocated(dev) - a0, 0)           # 0 when slot 0 existed already: then size it from the tensors
+        if first_ws == 0:
+            w0 = eng.workspace(nb0, patch_size, patch_size, dev, 0)
+            first_ws = sum(t.numel() * t.element_size() for d_ in (w0.z, w0.pool, w0.f, w0.U) for t in d_.values()) + w0.x0.numel() * w0.x0.element_size()
+        free_dev = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if two_streams is None and free_dev < 1.5 * first_ws:
+            want_two = False
+    lanes = [cur, _streams.get('wgrad', dev)] if want_two else [cur]
     seen = [set() for _ in lanes]
     if len(lanes) > 1:
         eng._weights(eng.layers[0], P, False)            # the filter images are packed once, on the caller's stream, before the fork
+        for nb_ in {min(batch_size, hi - lo), (hi - lo) % batch_size or batch_size}:
+            eng.workspace(nb_, patch_size, patch_size, dev, 1)             # second lane's buffers: allocated under the caller's stream
         lanes[1].wait_stream(cur)
         for t in (d1, d2, mask, origins):
             t.record_stream(lanes[1])
@@ -188,6 +204,8 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
     finally:
         for ln in lanes[1:]:
             cur.wait_stream(ln)
+        if len(lanes) > 1:
+            eng.drop_workspaces(slot=1)                  # back to the caller's pool (ordered behind the join above)
         if feed is not None:
             feed.close()          # also on an exception: the consumer stream joins every upload before the planes can be freed
     if shard is not None and merge and shard[1] > 1:

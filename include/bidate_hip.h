@@ -102,7 +102,7 @@ int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad,
  * convolves it with w_dgrad into dA_prev [N,H,W,Cout] and stores dz [N,H,W,C0] to dz_out (NULL: not stored) for the weight-gradient
  * GEMM -- bdn_bn_bwd_apply's pass over dA, z and dz does not run.  z_prev / bn_prev / bs_partial: as bdn_conv3x3_dgrad_bs, or all NULL.
  * bf16, C0 = 64 (a single channel chunk: the staging then runs once, in the kernel's prologue), maps larger than 8x8.  Measured in the
- * training step (tools/ab_fold.py): pays for the last full-resolution layer only (inc's second conv), which is where the engine uses it. */
+ * training step (tools/archive/ab_fold.py): pays for the last full-resolution layer only (inc's second conv), which is where the engine uses it. */
 int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const void* z, const float* bn, const float* sums, int imgs_per_group,
                          const void* w_dgrad, void* dA_prev, const void* z_prev, const float* bn_prev, float* bs_partial,
                          void* dz_out, int N, int H, int W, int Cout, void* stream);
@@ -245,6 +245,11 @@ int bdn_fuse_product(int dtype, const void* z, const float* bn, void* f,
  * f [B,H,W,C] = relu(a_d2*a_d1), pool [2B,H/2,W/2,C] = MaxPool2d(2)(a), a = relu(bn(z)), z [2B,H,W,C] date 1 first. */
 int bdn_product_pool(int dtype, const void* z, const float* bn, void* f, void* pool,
                      int B, int H, int W, int C, void* stream);
+/* The same pass writing the pooled maps of SOME dates only (pool_dates: bit 0 = date 1, bit 1 = date 2; f is always written): the
+ * two-chain forward runs the dates of models/bidate_model.py:23-33 on two streams, where the chain of date 2 forms the skip and its own
+ * pooled map while date 1's chain pools its own map with bdn_bnrelu_pool (same values, bit for bit). */
+int bdn_product_pool_dates(int dtype, const void* z, const float* bn, void* f, void* pool, int pool_dates,
+                           int B, int H, int W, int C, void* stream);
 
 /* bf16x3 setting (float32 z): both outputs stored directly as the [hi | lo] bf16 operands of the convolutions that consume them -- f into
  * channels [0, C) of the decoder stage's two-source operand f_split [B,H,W,f_ld] (lo half f_half channels further), pool as

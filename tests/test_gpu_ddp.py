@@ -13,6 +13,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -229,9 +230,109 @@ def test_guard_recovers_the_slow_collective_stream_arrangement(tmp_path):
     assert rep['state_restored'] and rep['loss_finite'], rep
     assert rep['ok'] and rep['overhead_frac'] <= 0.05, rep
     first = rep['tried'][0]['overhead_frac']
-    if first > 0.05:                      # the slow state was there (it is on every box measured so far): a remedy must have been applied
-        assert rep['recovered'] and any(rep['streams_replaced']) or rep['deferred_buckets'], rep
-    print(f"slow arrangement {first * 100:+.1f} % -> {rep['overhead_frac'] * 100:+.1f} % after {[t['remedy'] for t in rep['tried']]}")
+    print(f"provoked arrangement {first * 100:+.1f} % -> kept {rep['kept']!r} at {rep['overhead_frac'] * 100:+.1f} % after {[t['arrangement'] for t in rep['tried']]}")
+    if first <= 0.05:
+        # the provocation did not produce the slow state on THIS box: say so instead of passing silently -- the repair path was
+        # not exercised by hardware here (its decision logic is held by test_guard_decisions_on_scripted_timings either way)
+        pytest.skip(f'slow collective-stream arrangement NOT observed on this box (provoked overhead {first * 100:+.1f} %): repair path not exercised')
+    assert rep['placement_problem'] and rep['recovered'], rep
+    assert any(rep['streams_replaced']) or rep['deferred_buckets'], rep
+
+
+_GUARD_SCRIPTED = r'''
+import json, os, sys, warnings, torch
+sys.path.insert(0, sys.argv[1])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+from fabric_amd import BiDateNet, streams
+from fabric_amd.parallel import init_rccl
+from fabric_amd.train_step import TrainStep
+init_rccl(0, 1, dev)
+torch.manual_seed(0)
+model = BiDateNet(3, 2, precision='bf16').to(dev).train()
+out = {}
+
+def scenario(name, table, boom=False):
+    """table(enabled, defer, chain_replaced, wgrad_replaced) -> seconds per step: the guard's clock, scripted"""
+    ts = TrainStep(model, lr=1e-3, force_collectives=True, guard=False)
+    chain0, wgrad0 = streams.get('chain', dev), streams.get('wgrad', dev)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    calls = []
+    def fake(x1, x2, lbl, n, warm):
+        key = (ts.bucketer.enabled, ts.bucketer.defer, streams.get('chain', dev).cuda_stream != chain0.cuda_stream,
+               streams.get('wgrad', dev).cuda_stream != wgrad0.cuda_stream)
+        calls.append(key)
+        if boom and len(calls) == 3:
+            raise RuntimeError('scripted failure')
+        ts._step(x1, x2, lbl)                      # one real step, so that the restore has something to undo
+        return table(*key)
+    ts._time_steps = fake
+    rec = {}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        try:
+            rec['rep'] = ts.guard_collectives(4, 32, 32)
+        except RuntimeError as e:
+            rec['raised'] = str(e)
+        rec['warned'] = [str(x.message)[:60] for x in w if issubclass(x.category, RuntimeWarning)]
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    rec['state_restored'] = all(torch.equal(before[k], after[k]) for k in before)
+    rec['chain_is_original'] = streams.get('chain', dev).cuda_stream == chain0.cuda_stream
+    rec['wgrad_is_original'] = streams.get('wgrad', dev).cuda_stream == wgrad0.cuda_stream
+    rec['defer'] = bool(ts.bucketer.defer)
+    rec['enabled'] = bool(ts.bucketer.enabled)
+    rec['report_attr'] = ts.collectives_report if not isinstance(ts.collectives_report, dict) else 'dict'
+    rec['calls'] = len(calls)
+    ts.step(torch.randn(4, 3, 32, 32, device=dev), torch.randn(4, 3, 32, 32, device=dev), torch.zeros(4, 32, 32, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    streams.restore('chain', chain0, dev); streams.restore('wgrad', wgrad0, dev)       # next scenario starts from the same arrangement
+    out[name] = rec
+
+ms = 1e-3
+# A: the overhead is the exchange itself (deferred is worse than overlapped): nothing may change, nothing may be warned about
+scenario('exchange', lambda en, de, c, w: 6.0 * ms if not en else (7.0 * ms if de else 6.6 * ms))
+# B: placement problem that a new chain stream fixes
+scenario('fixed_by_chain', lambda en, de, c, w: 6.0 * ms if not en else (6.3 * ms if de else (6.05 * ms if c else (8.9 * ms if w else 9.0 * ms))))
+# C: placement problem that the stream remedies make worse: back to the ORIGINAL streams, buckets deferred, overhead = deferred's
+scenario('only_defer_helps', lambda en, de, c, w: 6.0 * ms if not en else (6.6 * ms if de else (9.6 * ms if c else (9.5 * ms if w else 9.0 * ms))))
+# D: the measurement itself fails
+scenario('failure', lambda en, de, c, w: 6.0 * ms, boom=True)
+print('SCRIPTED ' + json.dumps(out))
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+
+
+def test_guard_decisions_on_scripted_timings(tmp_path):
+    """TrainStep.guard_collectives' decision logic with its clock scripted (the hardware state it reacts to cannot be ordered up):
+    an overhead that is the exchange itself changes nothing and warns about nothing; a placement problem is repaired by the stream
+    remedy that measures best; remedies that measure worse are rolled back (streams.restore) before the buckets are deferred, and the
+    reported overhead is that of the arrangement actually kept; a failing measurement leaves no half-state behind."""
+    import json
+    script = tmp_path / 'guard_scripted.py'
+    script.write_text(_GUARD_SCRIPTED)
+    port = str(37000 + os.getpid() % 2000)
+    p = subprocess.Popen([sys.executable, str(script), ROOT, port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    txt = p.communicate(timeout=280)[0].decode()
+    assert p.returncode == 0, txt
+    out = json.loads([l for l in txt.splitlines() if l.startswith('SCRIPTED ')][-1][9:])
+    a, b, c, d = out['exchange'], out['fixed_by_chain'], out['only_defer_helps'], out['failure']
+    for r in (a, b, c, d):
+        assert r['state_restored'] and r['enabled'], r
+    ra = a['rep']
+    assert ra['placement_problem'] is False and ra['kept'] == 'original' and ra['ok'] and not ra['deferred_buckets'], ra
+    assert abs(ra['overhead_frac'] - 0.10) < 1e-6 and a['chain_is_original'] and a['wgrad_is_original'] and not a['warned'] and not a['defer'], a
+    rb = b['rep']
+    assert rb['placement_problem'] and rb['recovered'] and rb['kept'] == 'new_chain_stream' and not rb['deferred_buckets'], rb
+    assert abs(rb['overhead_frac'] - 0.05 / 6.0) < 1e-6 and not b['chain_is_original'] and not b['warned'], b
+    rc = c['rep']
+    assert rc['placement_problem'] and rc['kept'] == 'original + deferred_buckets' and rc['deferred_buckets'] and c['defer'], rc
+    assert c['chain_is_original'] and c['wgrad_is_original'], c                      # the remedies that measured worse were rolled back
+    assert abs(rc['overhead_frac'] - 0.10) < 1e-6 and not rc['ok'] and len(c['warned']) == 1, c      # reports what runs; still above 5 %: says so
+    assert d.get('raised') == 'scripted failure' and d['report_attr'] is None and not d['defer'], d
 
 
 def test_bench_two_ranks_end_to_end_on_one_device():
@@ -253,3 +354,28 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert d['config']['global_batch'] == 16 and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 2 * 8 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value'] and d['value'] > 0
     assert d['roofline'] is not None and d['step_classes'] is not None and 'cpu_baseline' not in d
+
+
+def test_bench_eight_ranks_rehearsal_on_one_device():
+    """BASELINE configs[2]'s launch -- `bench.py --gpus 8` under torch.distributed.run -- rehearsed with the one device a box has: eight
+    ranks share cuda:0 and exchange gradients over gloo (BENCH_BACKEND=gloo; RCCL refuses several ranks per device).  It exercises
+    everything of the 8-GPU run that is not the xGMI transfer itself: rank plumbing, the barrier / max-over-ranks timing, eight
+    bucketers cutting and launching the same five buckets, the broadcast, the JSON contract with n_gpus = 8 and global batch 8 x B.
+    Still "unmeasured on hardware" for scaling: this removes launch-logic surprises from the first real 8-GPU run, nothing more."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['BENCH_BACKEND'] = 'gloo'
+    env['OMP_NUM_THREADS'] = '2'
+    port = str(38000 + os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1', '--master-port', port,
+           os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '4', '--size', '64', '--windows', '2']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['steps'] == 2 and len(d['windows_ms_per_step']) == 2
+    assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp8' and 'configs[2]' in d['config']['workload']
+    assert abs(d['value'] - 8 * 4 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value'] and d['value'] > 0
+    assert d['roofline'] is not None and 'families' in d['roofline'] and 'cpu_baseline' not in d
+    assert np.isfinite(d['final_loss'])

@@ -152,6 +152,28 @@ def test_host_fed_scene_equals_resident_scene(pinned, band_rows):
     assert 0.02 < ref.float().mean().item() < 0.98
 
 
+@pytest.mark.parametrize('host', [False, True])
+def test_two_stream_scene_scan_equals_single_stream(host):
+    """predict_scene alternates tile batches between the caller's stream and the library's second stream (each with its own workspace):
+    the mask must equal the single-stream loop's bit for bit -- resident scenes and host scenes fed through the band feeder -- and
+    the second lane's workspace must be gone from the engine afterwards (its memory returns to the caller's allocator pool)."""
+    c, h, w, p = 13, 300, 260, 64
+    d1, d2 = _scene(c, h, w, 6)
+    model, _ = _calibrated_model(c, 'bf16', d1, d2, p)
+    t1, t2 = torch.from_numpy(d1), torch.from_numpy(d2)
+    if host:
+        t1, t2 = t1.pin_memory(), t2.pin_memory()
+    else:
+        t1, t2 = t1.cuda(), t2.cuda()
+    one = inf.predict_scene(model, t1, t2, patch_size=p, batch_size=6, two_streams=False, band_rows=32)
+    for bs in (6, 7):                                          # equal batches, ragged last batch
+        two = inf.predict_scene(model, t1, t2, patch_size=p, batch_size=bs, two_streams=True, band_rows=32)
+        auto = inf.predict_scene(model, t1, t2, patch_size=p, batch_size=bs, band_rows=32)
+        assert torch.equal(two, one) and torch.equal(auto, one)
+    assert not [k for k in model.engine()._ws if k[4] == 1], 'second-lane workspaces must be dropped on exit'
+    assert 0.02 < one.float().mean().item() < 0.98
+
+
 def test_predict_scene_full_size_properties():
     """BASELINE config-5 shape at a bounded size (13 bands, 128-pixel tiles, 1000 x 900): the sharded scan equals
     the single scan, the scan is reproducible, and it equals the reference-style patch loop."""

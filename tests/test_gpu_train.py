@@ -152,7 +152,7 @@ def test_two_chain_forward_is_bit_identical(prec, shape):
         return out + [v.clone() for v in model.state_dict().values()]
 
     ref = run(1, 0, 3)
-    for chains, defer, levels in ((2, 1, 3), (2, 0, 3), (2, 1, 2), (2, 1, 4), (2, 0, 1)):
+    for chains, defer, levels in ((2, 1, 3), (2, 0, 3), (2, 2, 3), (2, 1, 2), (2, 2, 4), (2, 0, 1), (2, 2, 1)):
         got = run(chains, defer, levels)
         assert len(got) == len(ref)
         for i, (a, r) in enumerate(zip(got, ref)):

@@ -277,20 +277,36 @@ for epoch in range(2):
     assert len(set(flat_idx)) == len(flat_idx) == (103 // world) * world          # disjoint; at most world - 1 items dropped
 assert gathered[0][0] != gathered[0][1]                                            # reshuffled per epoch
 dist.barrier(); dist.destroy_process_group()
+print('BUCKETS', [(a, e) for a, e, _ in b.buckets])
 print('ok', rank)
 '''
 
 
-def test_grad_bucketer_gloo_world2(tmp_path):
-    """N>1 path on CPU: two gloo ranks, bucketed async all-reduce over the flat gradient buffer."""
+@pytest.mark.parametrize('world', [2, 8])
+def test_grad_bucketer_gloo(tmp_path, world):
+    """N>1 path on CPU: `world` gloo ranks (2, and 8 = BASELINE configs[2]'s rank count), bucketed async all-reduce over the flat
+    gradient buffer, stride-by-rank shards, epoch-aware ShardSampler (disjoint, covering, reshuffled per epoch), and the SAME five
+    contiguous buckets on every rank and at every world size (what a rank launches must match what its peers launch)."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', ROOT, port],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    port = str(29500 + (os.getpid() + 17 * world) % 2000)
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), ROOT, port], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
     assert all('ok' in o for o in outs)
+    cuts = {[l for l in o.splitlines() if l.startswith('BUCKETS')][-1] for o in outs}
+    assert len(cuts) == 1, cuts
+    # and they are the cuts a process computes with no group at all (world-size independent)
+    from fabric_amd import BiDateNet
+    from fabric_amd.engine import param_order
+    from fabric_amd.parallel import FlatLayout, GradBucketer
+    m, order = BiDateNet(3, 2), param_order(3)
+    lay = FlatLayout([(k, p_.shape) for k, p_ in m.named_parameters()], order)
+    tail = [k for k in order if k.endswith('.bias') and k.split('.')[-2] in ('0', '3')]
+    b = GradBucketer(lay, torch.zeros(lay.total), n_buckets=4, keys_no_reduce=tail)
+    assert cuts.pop() == 'BUCKETS ' + str([(a, e) for a, e, _ in b.buckets])
 
 
 def test_inference_tiler_matches_golden(golden_dir):

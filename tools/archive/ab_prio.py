@@ -1,5 +1,5 @@
 """Stream priorities of the two queues of a training step (chain = forward / loss / dz chain / SGD, side = weight-gradient GEMMs):
-every combination of normal and high, in one process.  python tools/ab_prio.py"""
+every combination of normal and high, in one process.  python tools/archive/ab_prio.py"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

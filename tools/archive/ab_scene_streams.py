@@ -1,4 +1,4 @@
-"""Scene inference on one vs two streams (test infrastructure):  python tools/ab_scene_streams.py [size] [batch]"""
+"""Scene inference on one vs two streams (test infrastructure):  python tools/archive/ab_scene_streams.py [size] [batch]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 #!/bin/bash
-# build conv3x3 variants: tools/build_variants.sh name "-DF_X=0 ..." [name flags]...
+# build conv3x3 variants: tools/archive/build_variants.sh name "-DF_X=0 ..." [name flags]...
 cd /root/repo/fabric_amd/csrc && mkdir -p variants
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2

@@ -1,5 +1,5 @@
 // Probe (test infrastructure): cost of device-scope int64 atomics used as a deterministic cross-block reduction.
-//   hipcc --offload-arch=gfx950 -O3 tools/probe_atomics.hip -o tools/probe_atomics && tools/probe_atomics
+//   hipcc --offload-arch=gfx950 -O3 tools/archive/probe_atomics.hip -o tools/probe_atomics && tools/probe_atomics
 // 8192 blocks (the tile count of a full-resolution conv) x 128 no-return 64-bit adds each, into S slices of 128 addresses.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

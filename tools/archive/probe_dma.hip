@@ -1,6 +1,6 @@
 // Pins the LDS-DMA semantics wgrad6 relies on (gfx950): `buffer_load_dwordx4 v, s[0:3], 0 offen lds` writes lane l's 16 bytes
 // to LDS byte (M0 + 16 l) whatever the lane's source offset is, and a lane whose offset lies beyond the descriptor's
-// num_records gets ZEROS written (not skipped).   hipcc --offload-arch=gfx950 -O2 tools/probe_dma.hip -o tools/probe_dma && tools/probe_dma
+// num_records gets ZEROS written (not skipped).   hipcc --offload-arch=gfx950 -O2 tools/archive/probe_dma.hip -o tools/probe_dma && tools/probe_dma
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

@@ -1,5 +1,5 @@
 // What does an event record between two dependent kernels cost the recording stream, and does attaching the event to the
-// kernel's own dispatch packet (hipExtLaunchKernelGGL stopEvent) avoid it?   hipcc --offload-arch=gfx950 -O2 tools/probe_event.hip -o tools/probe_event
+// kernel's own dispatch packet (hipExtLaunchKernelGGL stopEvent) avoid it?   hipcc --offload-arch=gfx950 -O2 tools/archive/probe_event.hip -o tools/probe_event
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>

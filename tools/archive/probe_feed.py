@@ -1,4 +1,4 @@
-"""Host-fed vs resident step time, alternated inside one process (test infrastructure).  python tools/probe_feed.py"""
+"""Host-fed vs resident step time, alternated inside one process (test infrastructure).  python tools/archive/probe_feed.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

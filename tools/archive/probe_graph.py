@@ -1,4 +1,4 @@
-"""Does hipGraph capture of the whole training step change its duration?  (test infrastructure)  python tools/probe_graph.py"""
+"""Does hipGraph capture of the whole training step change its duration?  (test infrastructure)  python tools/archive/probe_graph.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 """Which HIP streams share a hardware queue?  (test infrastructure)  Streams are created in order -- n normal-priority and h high-priority ones through
 bdn_stream_create, plus torch's default stream -- and every pair is probed: a long sleep kernel on A, a tiny kernel on B; if B's kernel finishes only
-after A's, the two are serialised, i.e. they sit on one hardware queue.   python tools/probe_queues.py [n_normal=6] [n_high=3]"""
+after A's, the two are serialised, i.e. they sit on one hardware queue.   python tools/archive/probe_queues.py [n_normal=6] [n_high=3]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 """Provoke the slow RCCL stream arrangement (round 3: +48...+59 % step time) and watch TrainStep.guard_collectives deal with it.
 
-    python tools/probe_rccl_guard.py [slow|fast]
+    python tools/archive/probe_rccl_guard.py [slow|fast]
 
 slow: the step's streams exist BEFORE the process group, whose collective stream is HIGH priority (the one combination that measured
 slow); fast: group first, default priority (what bench.py / train.py do).  One rank, buckets forced.  Prints the guard's report."""

@@ -11,7 +11,7 @@ applied to the layers a reduced-work kernel would serve (Cin >= 128 and Cout >= 
 |logit - float32 oracle| on the golden-vector inputs G2 (13 bands, 128x128, B = 2) and G6 (dates from different distributions);
 tests/test_gpu_model.py's bf16 bound is max 0.25 / mean 0.03.
 
-    python tools/probe_winograd_numerics.py
+    python tools/archive/probe_winograd_numerics.py
 """
 import os
 import sys

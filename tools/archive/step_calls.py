@@ -1,4 +1,4 @@
-"""Per-entry-point time of one instrumented training step (test infrastructure):  python tools/step_calls.py [precision]"""
+"""Per-entry-point time of one instrumented training step (test infrastructure):  python tools/archive/step_calls.py [precision]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-"""Phase anatomy of one conv3x3 launch (apply tools/experimental/conv_stamp.patch, then tools/build_variants.sh stamp "-DSTAMP"): every wave writes its
+"""Phase anatomy of one conv3x3 launch (apply tools/experimental/conv_stamp.patch, then tools/archive/build_variants.sh stamp "-DSTAMP"): every wave writes its
 cycle-counter stamps into its tile's statistics row.  BIDATE_LIB=fabric_amd/csrc/variants/lib_stamp.so python tools/stamp_conv.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
