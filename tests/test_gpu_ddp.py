@@ -265,7 +265,7 @@ def scenario(name, table, boom=False, exchange=0.05e-3):
         key = (ts.bucketer.enabled, ts.bucketer.defer, streams.get('chain', dev).cuda_stream != chain0.cuda_stream,
                streams.get('wgrad', dev).cuda_stream != wgrad0.cuda_stream)
         calls.append(key)
-        if boom and len(calls) == 3:
+        if boom and len(calls) == 2:
             raise RuntimeError('scripted failure')
         ts._step(x1, x2, lbl)                      # one real step, so that the restore has something to undo
         return table(*key)

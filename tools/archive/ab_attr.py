@@ -1,6 +1,6 @@
 """In-process A/B of a module-level switch of fabric_amd.engine (test infrastructure):  python tools/archive/ab_attr.py NAME v0 v1 ..."""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet, engine
 from fabric_amd.train_step import TrainStep

@@ -1,6 +1,6 @@
 """In-process A/B of a boolean / integer engine attribute:  python tools/archive/ab_flag.py pair_wgrad_handoff 0 1"""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep

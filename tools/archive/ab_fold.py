@@ -1,6 +1,6 @@
 """In-process A/B of engine.fold_bn_bwd (BatchNorm backward applied inside the data-gradient conv):  python tools/archive/ab_fold.py "" d4a d4a,d3a,d3b ..."""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep

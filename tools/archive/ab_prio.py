@@ -1,7 +1,7 @@
 """Stream priorities of the two queues of a training step (chain = forward / loss / dz chain / SGD, side = weight-gradient GEMMs):
 every combination of normal and high, in one process.  python tools/archive/ab_prio.py"""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep

@@ -1,6 +1,6 @@
 """Scene inference on one vs two streams (test infrastructure):  python tools/archive/ab_scene_streams.py [size] [batch]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.utils import inference as inf

@@ -1,6 +1,6 @@
 """Time bdn_enc_skip_bwd on the five encoder levels of the benchmark shape (test infrastructure)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import _lib
 B = 64

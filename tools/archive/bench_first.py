@@ -1,6 +1,6 @@
 """The first conv's fused BatchNorm-backward + weight-gradient GEMM alone, against the two-kernel path (apply + simple wgrad)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import _lib
 lib = _lib.load(); st = _lib.stream_ptr(); dt = 1; td = torch.bfloat16

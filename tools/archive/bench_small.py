@@ -1,6 +1,6 @@
 """Micro-benchmark (test infrastructure) of the HBM-bound stage kernels at the B=64 128x128 shapes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import _lib
 dt, td = _lib.BDN_BF16, torch.bfloat16

@@ -1,6 +1,6 @@
 """Time the weight-gradient split-K GEMM and its reduction separately (bdn_conv3x3_wgrad_ex phases 1 / 2)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import _lib
 from fabric_amd.engine import build_layers, ENC_CH

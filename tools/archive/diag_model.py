@@ -1,7 +1,7 @@
 """Diagnostic (test infrastructure): per-layer forward and per-parameter gradient errors of the HIP
 engine vs the CPU oracle on one small configuration.  Usage: python tools/archive/diag_model.py [prec] [C B S]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.engine import build_layers

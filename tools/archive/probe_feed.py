@@ -1,6 +1,6 @@
 """Host-fed vs resident step time, alternated inside one process (test infrastructure).  python tools/archive/probe_feed.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep

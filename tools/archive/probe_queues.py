@@ -2,7 +2,7 @@
 bdn_stream_create, plus torch's default stream -- and every pair is probed: a long sleep kernel on A, a tiny kernel on B; if B's kernel finishes only
 after A's, the two are serialised, i.e. they sit on one hardware queue.   python tools/archive/probe_queues.py [n_normal=6] [n_high=3]"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import _lib, streams
 n_norm = int(sys.argv[1]) if len(sys.argv) > 1 else 6

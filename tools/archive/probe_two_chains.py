@@ -1,7 +1,7 @@
 """Would two independent half-batch chains overlap better than one full-batch chain?  (test infrastructure)
 arg: one64 | one32 | two32"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep

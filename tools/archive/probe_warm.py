@@ -1,6 +1,6 @@
 """Does the step time drift over the life of a process?  (test infrastructure)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet
 from fabric_amd.train_step import TrainStep

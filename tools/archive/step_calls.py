@@ -1,6 +1,6 @@
 """Per-entry-point time of one instrumented training step (test infrastructure):  python tools/archive/step_calls.py [precision]"""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fabric_amd import BiDateNet, _lib
 from fabric_amd.train_step import TrainStep
