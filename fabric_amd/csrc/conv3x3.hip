@@ -38,12 +38,14 @@ struct ConvArgs {
     int tiles_y, tiles_x, n_ntiles;
     // data-gradient launches only: the output is dA of the layer whose raw output is bs_z and whose BatchNorm table
     // is bs_bn; the epilogue then also emits that layer's BatchNorm-backward partial sums (stats_partial, same
-    // [n_mtiles][2][Cout] layout):  sum_p g  and  sum_p g*z  with  g = dA * [scale*z + shift > 0]
+    // [n_mtiles][2][Cout] layout):  sum_p g  and  sum_p g*z  with  g = dA * [scale*z + shift > 0], and what it stores is g (masked)
     const void* bs_z; const float* bs_bn;
-    // data-gradient launches with the BatchNorm+ReLU backward of THIS layer applied while the input is staged (template flag BB; round 4):
-    // in0 = dA (gradient wrt relu(bn(z))), bb_z = the layer's raw output z [N,H,W,C0], bb_bn its table, bb_sums [G][2][C0] from
-    // bdn_bn_bwd_finalize; the staged operand is dz = scale * (g - s0/M - xhat * s1/M), g = dA * [scale z + shift > 0] -- bdn_bn_bwd_apply's
-    // expression, value for value -- and the blocks of column tile 0 also store their tile's dz to bb_dz (for the weight-gradient GEMM)
+    // data-gradient launches with the BatchNorm+ReLU backward of THIS layer applied while the input is staged (template flag BB; round 4,
+    // three-constant form round 5): in0 = g, the MASKED gradient g = dA * [scale z + shift > 0] exactly as every fused producer stores it
+    // (dgrad_bs epilogue below, bdn_enc_skip_bwd, bdn_upsample2x_bwd_bs), bb_z = the layer's raw output z [N,H,W,C0], bb_bn its table,
+    // bb_sums [G][2][C0] from bdn_bn_bwd_finalize; the staged operand is dz = a g + b z + c with the per-channel constants
+    //   a = scale,  b = -scale invstd s1/M,  c = -scale s0/M - b mean      ( = scale (g - s0/M - xhat s1/M), bdn_bn_bwd_apply's value up to
+    // rounding) -- two FMAs per element, no compare, three constants -- and the blocks of column tile 0 also store their tile's dz to bb_dz
     const void* bb_z; const float* bb_bn; const float* bb_sums; void* bb_dz; float bb_invM;
 };
 
@@ -202,25 +204,27 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
             const float* ph_ = bn_row(a.in_bn, grp, 3, a.C0) + bc_ + p_sub;                             \
             _Pragma("unroll") for (int e = 0; e < EPU; e++) { sc_[e] = ps_[e]; sh_[e] = ph_[e]; }        \
         }                                                                                               \
-        float bk_[BB ? 6 : 1][EPU];                        /* BB: mean, invstd, scale, shift, s0/M, s1/M of this thread's channels */ \
+        float bk_[BB ? 3 : 1][EPU];                        /* BB: a, b, c of this thread's channels (see ConvArgs) */ \
         if constexpr (BB) {                                                                             \
-            _Pragma("unroll") for (int k = 0; k < 4; k++) {                                              \
-                const float* r_ = bn_row(a.bb_bn, grp, k, a.C0) + bc_ + p_sub;                          \
-                _Pragma("unroll") for (int e = 0; e < EPU; e++) bk_[k][e] = r_[e];                       \
-            }                                                                                           \
-            _Pragma("unroll") for (int k = 0; k < 2; k++) {                                              \
-                const float* r_ = a.bb_sums + ((size_t)grp * 2 + k) * a.C0 + bc_ + p_sub;               \
-                _Pragma("unroll") for (int e = 0; e < EPU; e++) bk_[4 + k][e] = r_[e] * a.bb_invM;        \
+            {                                                                                           \
+                const float* rm_ = bn_row(a.bb_bn, grp, 0, a.C0) + bc_ + p_sub;                         \
+                const float* ri_ = bn_row(a.bb_bn, grp, 1, a.C0) + bc_ + p_sub;                         \
+                const float* rs_ = bn_row(a.bb_bn, grp, 2, a.C0) + bc_ + p_sub;                         \
+                const float* s0_ = a.bb_sums + ((size_t)grp * 2 + 0) * a.C0 + bc_ + p_sub;              \
+                const float* s1_ = a.bb_sums + ((size_t)grp * 2 + 1) * a.C0 + bc_ + p_sub;              \
+                _Pragma("unroll") for (int e = 0; e < EPU; e++) {                                        \
+                    const float sc1_ = rs_[e];                                                          \
+                    bk_[0][e] = sc1_;                                                                   \
+                    bk_[1][e] = -(sc1_ * ri_[e]) * (s1_[e] * a.bb_invM);                                \
+                    bk_[2][e] = fmaf(-bk_[1][e], rm_[e], -(sc1_ * (s0_[e] * a.bb_invM)));               \
+                }                                                                                       \
             }                                                                                           \
             _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                            \
                 float fz_[EPU], fg_[EPU], o_[EPU];                                                      \
                 Unit<T>::unpack(pregz[i], fz_);                                                         \
                 Unit<T>::unpack(preg[i], fg_);                                                          \
-                _Pragma("unroll") for (int e = 0; e < EPU; e++) {                                        \
-                    const float gm_ = fmaf(fz_[e], bk_[2][e], bk_[3][e]) > 0.f ? fg_[e] : 0.f;           \
-                    const float xh_ = (fz_[e] - bk_[0][e]) * bk_[1][e];                                  \
-                    o_[e] = bk_[2][e] * (gm_ - bk_[4][e] - xh_ * bk_[5][e]);                             \
-                }                                                                                       \
+                _Pragma("unroll") for (int e = 0; e < EPU; e++)                                          \
+                    o_[e] = fmaf(fg_[e], bk_[0][e], fmaf(fz_[e], bk_[1][e], bk_[2][e]));                 \
                 preg[i] = Unit<T>::pack(o_);                                                            \
                 if (a.bb_dz != nullptr && ntile == 0 && p_pix[i] >= 0) {      /* the tile's own pixels: the weight-gradient GEMM reads them */ \
                     const int u_ = tid + i * 256, pix_ = u_ / UPP, xx_ = pix_ % TL::PW, yy_ = (pix_ / TL::PW) % TL::PH;   \
@@ -466,16 +470,18 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     if ((o_) != 0xffffffffu) {                                                                          \
         const int u_ = tid + (i_) * 256;                                                                \
         uint4 v = *reinterpret_cast<const uint4*>(otile + (u_ / UPR) * CF::OSTR + (u_ % UPR) * 16);     \
-        *reinterpret_cast<uint4*>(outp + (o_)) = v;                                                     \
-        if (bs) {                                            /* the stored (rounded) gradient is what BatchNorm backward sees */ \
-            float fg[OEPU], fz[OEPU];                                                                   \
-            Unit<TO>::unpack(v, fg);                                                                    \
+        if (bs) {                                            /* the stored (rounded) gradient is what BatchNorm backward sees; it leaves */ \
+            float fg[OEPU], fz[OEPU];                        /* MASKED: g = dA * [scale z + shift > 0] -- every consumer applies the same */ \
+            Unit<TO>::unpack(v, fg);                         /* mask again (idempotent), the on-load BatchNorm backward (BB) relies on it  */ \
             Unit<TO>::unpack(zexpr_, fz);                                                               \
             _Pragma("unroll") for (int e = 0; e < OEPU; e++) {                                           \
                 const float g = fmaf(fz[e], bsc[e], bsh[e]) > 0.f ? fg[e] : 0.f;                        \
                 bs0[e] += g; bs1[e] = fmaf(g, fz[e], bs1[e]);                                           \
+                fg[e] = g;                                                                              \
             }                                                                                           \
+            v = Unit<TO>::pack(fg);                          /* exact: the values are already rounded */ \
         }                                                                                               \
+        *reinterpret_cast<uint4*>(outp + (o_)) = v;                                                     \
     }
     if constexpr (PRE) {
 #pragma unroll
@@ -690,7 +696,8 @@ extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const voi
 }
 
 // Data gradient of layer L with L's BatchNorm+ReLU backward applied while dz is staged (bdn_bn_bwd_apply never runs, dz is written once
-// as a by-product for the weight-gradient GEMM): dA [N,H,W,C0] (ldA == C0), z / bn / sums of layer L (sums from bdn_bn_bwd_finalize).
+// as a by-product for the weight-gradient GEMM): dA = the MASKED gradient g [N,H,W,C0] (ldA == C0) as stored by bdn_conv3x3_dgrad_bs /
+// bdn_enc_skip_bwd / bdn_upsample2x_bwd_bs, z / bn / sums of layer L (sums from bdn_bn_bwd_finalize).
 // z_prev / bn_prev / bs_partial: as bdn_conv3x3_dgrad_bs (all three NULL: no fused statistics of the producing layer).
 extern "C" int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const void* z, const float* bn, const float* sums, int imgs_per_group,
                                     const void* w_dgrad, void* dA_prev, const void* z_prev, const float* bn_prev, float* bs_partial,

@@ -499,10 +499,9 @@ __global__ __launch_bounds__(UB == 8 ? 512 : 256) void upsample2x_bwd_tiled_kern
                 for (int i = 0; i < EPU; i++) o[i] += wgt * f[i];
             }
         }
-        const uint4 ou = Unit<T>::pack(o);
-        *reinterpret_cast<uint4*>(dsrc + ((size_t)(n * h + y) * w + x) * C + c0 + uu * EPU) = ou;
-        if (bs) {                                                  // on the STORED (rounded) gradient, like every other producer
-            float g[EPU], fz[EPU];
+        uint4 ou = Unit<T>::pack(o);
+        if (bs) {                                                  // on the (rounded) gradient, like every other producer -- and what is
+            float g[EPU], fz[EPU];                                 // stored is g, MASKED (bidate_hip.h, bdn_conv3x3_dgrad_bs)
             Unit<T>::unpack(ou, g);
             Unit<T>::unpack(zq, fz);
             const float* ps = bn_row(bn_prev, 0, 2, C) + c0 + uu * EPU;
@@ -511,8 +510,11 @@ __global__ __launch_bounds__(UB == 8 ? 512 : 256) void upsample2x_bwd_tiled_kern
             for (int i = 0; i < EPU; i++) {
                 const float gg = fmaf(fz[i], ps[i], ph[i]) > 0.f ? g[i] : 0.f;
                 s0[i] = gg; s1[i] = gg * fz[i];
+                g[i] = gg;
             }
+            ou = Unit<T>::pack(g);
         }
+        *reinterpret_cast<uint4*>(dsrc + ((size_t)(n * h + y) * w + x) * C + c0 + uu * EPU) = ou;
     }
     if (bs) {
         // 64 source pixels per channel unit: lanes uu, uu + UB, ... of a wave hold the same channels -- butterfly over those lane bits,
@@ -676,19 +678,21 @@ __global__ __launch_bounds__(256, 1) void enc_skip_bwd_kernel(const T* __restric
                     if (pooled && ((idx0 >> (2 * i)) & 3u) == (unsigned)k) o0[i] += g0[i];
                     if (pooled && ((idx1 >> (2 * i)) & 3u) == (unsigned)k) o1[i] += g1[i];
                 }
-                const V u0 = U::pack(o0), u1 = U::pack(o1);
-                *reinterpret_cast<V*>(dA + p0 * C + c) = u0;
-                *reinterpret_cast<V*>(dA + p1 * C + c) = u1;
+                V u0 = U::pack(o0), u1 = U::pack(o1);
                 if (bs) {
-                    U::unpack(u0, o0); U::unpack(u1, o1);       // what BatchNorm backward will read back
+                    U::unpack(u0, o0); U::unpack(u1, o1);       // what BatchNorm backward will read back (rounded) ...
 #pragma unroll
                     for (int i = 0; i < EPU; i++) {
                         const float m0 = fmaf(f0[i], sc0[i], sh0[i]) > 0.f ? o0[i] : 0.f;
                         const float m1 = fmaf(f1[i], sc1[i], sh1[i]) > 0.f ? o1[i] : 0.f;
                         t00[i] += m0; t01[i] = fmaf(m0, f0[i], t01[i]);
                         t10[i] += m1; t11[i] = fmaf(m1, f1[i], t11[i]);
+                        o0[i] = m0; o1[i] = m1;
                     }
+                    u0 = U::pack(o0); u1 = U::pack(o1);         // ... and MASKED: the stored gradient is g (bidate_hip.h, bdn_conv3x3_dgrad_bs)
                 }
+                *reinterpret_cast<V*>(dA + p0 * C + c) = u0;
+                *reinterpret_cast<V*>(dA + p1 * C + c) = u1;
             }
         }
     }

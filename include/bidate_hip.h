@@ -91,18 +91,21 @@ const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, 
  * statistics of the PRODUCING layer fused into the epilogue: dz [N,H,W,C0] x rotated filter image w_dgrad ->
  * dA [N,H,W,Cout] (gradient wrt relu(bn(z_prev))), and bs_partial [bdn_conv3x3_num_mtiles(N,H,W,Cout,ipg)][2][Cout] =
  * per-tile sum g, sum g*z_prev with g = dA * [scale*z_prev + shift > 0] (z_prev [N,H,W,Cout], bn_prev [G][4][Cout]).
- * Tiles are image-major, so a statistic group owns num_mtiles/G consecutive rows: feed bdn_bn_bwd_apply(raw_moment=1). */
+ * What is STORED to dA is g, the masked gradient (zero where relu(bn(z_prev)) is off): every BatchNorm-backward consumer applies the
+ * same mask again (idempotent), and bdn_conv3x3_dgrad_bb expects it.  The same holds for bdn_enc_skip_bwd (with bs_partial) and
+ * bdn_upsample2x_bwd_bs.  Tiles are image-major, so a statistic group owns num_mtiles/G consecutive rows: feed bdn_bn_bwd_apply(raw_moment=1). */
 int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad, void* dA,
                          const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
                          int N, int H, int W, int Cout, void* stream);
 
 /* Data gradient of layer L's convolution with L's BatchNorm+ReLU backward (autograd of models/unet_parts.py:14-15,17-18) applied while the
- * operand is staged: dA [N,H,W,C0] = gradient wrt relu(bn(z)), z [N,H,W,C0], bn [G][4][C0], sums [G][2][C0] from bdn_bn_bwd_finalize;
- * the kernel forms dz = scale*(g - s0/M - xhat*s1/M), g = dA*[scale z + shift > 0] (bdn_bn_bwd_apply's expression, value for value),
- * convolves it with w_dgrad into dA_prev [N,H,W,Cout] and stores dz [N,H,W,C0] to dz_out (NULL: not stored) for the weight-gradient
- * GEMM -- bdn_bn_bwd_apply's pass over dA, z and dz does not run.  z_prev / bn_prev / bs_partial: as bdn_conv3x3_dgrad_bs, or all NULL.
- * bf16, C0 = 64 (a single channel chunk: the staging then runs once, in the kernel's prologue), maps larger than 8x8.  Measured in the
- * training step (tools/archive/ab_fold.py): pays for the last full-resolution layer only (inc's second conv), which is where the engine uses it. */
+ * operand is staged: dA [N,H,W,C0] = the MASKED gradient g = dA*[scale z + shift > 0] as the fused producers store it (see
+ * bdn_conv3x3_dgrad_bs), z [N,H,W,C0], bn [G][4][C0], sums [G][2][C0] from bdn_bn_bwd_finalize; the kernel forms
+ * dz = a g + b z + c with a = scale, b = -scale invstd s1/M, c = -scale s0/M - b mean (= bdn_bn_bwd_apply's scale*(g - s0/M - xhat*s1/M)
+ * up to rounding: two FMAs per element, three per-channel constants, no compare), convolves it with w_dgrad into dA_prev [N,H,W,Cout]
+ * and stores dz [N,H,W,C0] to dz_out (NULL: not stored) for the weight-gradient GEMM -- bdn_bn_bwd_apply's pass over dA, z and dz does
+ * not run.  z_prev / bn_prev / bs_partial: as bdn_conv3x3_dgrad_bs, or all NULL.
+ * bf16, C0 = 64 (a single channel chunk: the staging then runs once, in the kernel's prologue), maps larger than 8x8. */
 int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const void* z, const float* bn, const float* sums, int imgs_per_group,
                          const void* w_dgrad, void* dA_prev, const void* z_prev, const float* bn_prev, float* bs_partial,
                          void* dz_out, int N, int H, int W, int Cout, void* stream);
@@ -272,7 +275,7 @@ int bdn_upsample2x_bwd(int dtype, const void* dU, int ldU, void* dsrc,
 /* The same with the BatchNorm-backward partial sums of the layer whose relu(bn(z_prev)) had been upsampled (up's input x1 is the
  * previous double_conv's output, models/unet_parts.py:64-66 after :16-18) fused in: bs_partial f32
  * [bdn_upsample2x_bwd_rows(dtype,B,h,w,C)][2][C] = per block sum g, sum g*z_prev with g = dsrc * [scale*z_prev + shift > 0]
- * (z_prev [B,h,w,C], bn_prev [1][4][C]; one statistic group) -> bdn_bn_bwd_apply(raw_moment = 1).  rows() is 0 for shapes the
+ * (z_prev [B,h,w,C], bn_prev [1][4][C]; one statistic group) -> bdn_bn_bwd_apply(raw_moment = 1); dsrc holds g (masked).  rows() is 0 for shapes the
  * tiled kernel does not take (maps below 8x8, C not a multiple of 32 (bf16) / 16 (f32)): use bdn_upsample2x_bwd + bdn_bn_bwd there. */
 int bdn_upsample2x_bwd_rows(int dtype, int B, int h, int w, int C);
 int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* dsrc, const void* z_prev, const float* bn_prev,
@@ -285,7 +288,8 @@ int bdn_upsample2x_bwd_bs(int dtype, const void* dU, int ldU, void* dsrc, const 
 int bdn_enc_skip_bwd(int dtype, const void* dF, int ldF, const void* z, const float* bn,
                      const void* dP, void* dA, float* bs_partial, int B, int H, int W, int C, void* stream);
 /* bs_partial: NULL, or f32 [2][bdn_enc_skip_bwd_rows(dtype,B,H,W,C)][2][C] receiving the BatchNorm-backward partial
- * sums of the layer (per block: sum g, sum g*z; date 1 rows then date 2 rows) -> bdn_bn_bwd_apply(raw_moment = 1). */
+ * sums of the layer (per block: sum g, sum g*z; date 1 rows then date 2 rows) -> bdn_bn_bwd_apply(raw_moment = 1); dA then holds
+ * the MASKED gradient g = dA * [relu(bn(z)) > 0] (see bdn_conv3x3_dgrad_bs). */
 int bdn_enc_skip_bwd_rows(int dtype, int B, int H, int W, int C);
 
 /* ---- outconv: nn.Conv2d(64, n_classes, 1), models/unet_parts.py:86 ----

@@ -93,3 +93,25 @@ def bnrelu_ref(precision, z_nchw, bn, ipg):
         s = slice(g * ipg, (g + 1) * ipg)
         out[s] = torch.relu(z_nchw[s] * bn[g, 2][None, :, None, None] + bn[g, 3][None, :, None, None])
     return rnd(precision, out)
+
+
+def preact(z_nchw, bn, ipg):
+    """scale*z + shift per statistic group in float64 (the argument of the ReLU whose mask the fused producers apply)."""
+    out = torch.empty_like(z_nchw, dtype=torch.float64)
+    for g in range(bn.shape[0]):
+        s = slice(g * ipg, (g + 1) * ipg)
+        out[s] = z_nchw[s].double() * bn[g, 2].double()[None, :, None, None] + bn[g, 3].double()[None, :, None, None]
+    return out
+
+
+def assert_masked(name, got_nchw, full_nchw, pre, eps=1e-4):
+    """The fused producers store the MASKED gradient g = dA * [scale z + shift > 0] (include/bidate_hip.h, bdn_conv3x3_dgrad_bs): `got` must
+    equal `full` bit for bit where the ReLU is clearly on, be exactly zero where it is clearly off, and be one of the two within `eps`
+    of the switching point (the device evaluates the pre-activation with one FMA in float32)."""
+    got, full = got_nchw.double(), full_nchw.double()
+    on, off = pre > eps, pre < -eps
+    assert torch.equal(got[on], full[on]), f'{name}: stored gradient differs where the ReLU is on'
+    assert (got[off] == 0).all(), f'{name}: stored gradient not zero where the ReLU is off'
+    edge = ~(on | off)
+    assert ((got[edge] == full[edge]) | (got[edge] == 0)).all(), f'{name}: stored gradient at the switching point is neither g nor 0'
+    assert on.any() and off.any(), f'{name}: degenerate mask'

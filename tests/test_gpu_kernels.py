@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from fabric_amd import _lib
 from fabric_amd._lib import BDN_BF16, IN_BNRELU, IN_PLAIN
 from oracle import bidate_oracle as O
-from tests.gpu_util import (DT, assert_close, bn_table, bnrelu_ref, dev, frag_to_dense, from_nhwc, pack_w, rnd, st,
+from tests.gpu_util import (DT, assert_close, assert_masked, preact, bn_table, bnrelu_ref, dev, frag_to_dense, from_nhwc, pack_w, rnd, st,
                             to_nhwc)
 
 pytestmark = pytest.mark.gpu
@@ -123,15 +123,18 @@ def test_conv3x3_dgrad(prec, case):
 @pytest.mark.parametrize('case', [(2, 40, 24, 64, 64, 1, True), (4, 32, 32, 64, 128, 2, False), (2, 24, 20, 64, 64, 2, False),
                                   (16, 64, 64, 64, 256, 8, True), (3, 17, 45, 64, 128, 3, True)])
 def test_conv3x3_dgrad_with_bn_backward_on_load(case):
-    """bdn_conv3x3_dgrad_bb = bdn_bn_bwd_apply + bdn_conv3x3(_dgrad_bs) without the pass in between: dz (the by-product) and the data
-    gradient must equal the two-kernel path BIT FOR BIT (same expression, same operand values, same MFMA order), with and without the
-    fused BatchNorm-backward statistics of the producing layer; the three single-chunk instantiations, ragged tiles."""
+    """bdn_conv3x3_dgrad_bb = bdn_bn_bwd_apply + bdn_conv3x3(_dgrad_bs) without the pass in between.  Its operand is the MASKED gradient g
+    the fused producers store, and it forms dz = a g + b z + c (three per-channel constants, round 5) instead of bdn_bn_bwd_apply's
+    scale (g - s0/M - xhat s1/M): the same value up to float32 rounding, so dz (the by-product) and the data gradient are held to the
+    kernel tolerances against the two-kernel path, with and without the fused BatchNorm-backward statistics of the producing layer; the
+    three single-chunk instantiations, ragged tiles."""
     N, H, W, C0, Cout, ipg, with_bs = case
     lib = _lib.load()
     G = N // ipg
-    dA = rnd('bf16', _rand((N, C0, H, W), 61))
     z = rnd('bf16', _rand((N, C0, H, W), 62))
     bn = bn_table(G, C0, 63)
+    pre = preact(z, bn, ipg)
+    dA = rnd('bf16', _rand((N, C0, H, W), 61)) * (pre > 1e-4)         # g: masked, and zero at the switching point whichever way it rounds
     w = rnd('bf16', _rand((C0, Cout, 3, 3), 64, 0.05))          # layer L: Cout -> C0 channels; its data gradient maps C0 -> Cout
     _, wd = pack_w('bf16', w, Cout)
     dA_d, z_d, bn_d = to_nhwc('bf16', dA), to_nhwc('bf16', z), dev(bn)
@@ -160,16 +163,26 @@ def test_conv3x3_dgrad_with_bn_backward_on_load(case):
               out.data_ptr(), zp.data_ptr() if with_bs else None, bnp.data_ptr() if with_bs else None, part.data_ptr() if with_bs else None,
               dz.data_ptr(), N, H, W, Cout, st())
     torch.cuda.synchronize()
-    assert torch.equal(dz, dz_ref), (dz.float() - dz_ref.float()).abs().max()
-    assert torch.equal(out, out_ref), (out.float() - out_ref.float()).abs().max()
+    # dz: two roundings of nearly the same float32 value -- equal, or one bf16 step apart
+    assert_close('dz (a g + b z + c)', dz.float().cpu(), dz_ref.float().cpu(), 8e-3)
+    assert (dz.float() - dz_ref.float()).abs().max() <= 2.0 ** -7 * dz_ref.float().abs().max()
+    same = (dz == dz_ref).float().mean().item()
+    assert same > 0.9, f'only {same:.3f} of the dz values are bit-identical to bn_bwd_apply'
+    # the data gradient of two operands that differ by single bf16 steps in a few percent of the entries
+    live = out_ref.float() != 0 if with_bs else torch.ones_like(out_ref, dtype=torch.bool)       # the fused statistics store the masked gradient
+    assert_close('dA_prev', out.float().cpu(), out_ref.float().cpu(), 8e-3)
     if with_bs:
-        assert torch.equal(part, part_ref)
-    # without the by-product store the data gradient is the same
+        assert torch.equal(out == 0, out_ref == 0) or ((out == 0) != (out_ref == 0)).float().mean() < 1e-3
+        assert_close('fused statistics', part.cpu(), part_ref.cpu(), 2e-2, abs_floor=1e-3)
+    # without the by-product store the data gradient is the same, bit for bit
     out2 = torch.empty_like(out)
     _lib.call('bdn_conv3x3_dgrad_bb', BDN_BF16, dA_d.data_ptr(), C0, z_d.data_ptr(), bn_d.data_ptr(), sums.data_ptr(), ipg, wd.data_ptr(),
               out2.data_ptr(), None, None, None, None, N, H, W, Cout, st())
     torch.cuda.synchronize()
-    assert torch.equal(out2, out_ref)
+    if with_bs:
+        assert torch.equal(out2[out != 0], out[out != 0])       # the unmasked launch stores dA where the masked one stores g = dA
+    else:
+        assert torch.equal(out2, out)
 
 
 # ------------------------------------------------------------------ weight gradient
@@ -370,8 +383,8 @@ def test_upsample2x_and_backward(prec, case, bnrelu):
     _lib.call('bdn_upsample2x_bwd_bs', dt, dU_d.data_ptr() + extra * es, C + extra, dsrc2.data_ptr(), zp_d.data_ptr(), bnp_d.data_ptr(),
               part.data_ptr(), B, h, w, H, W, C, st())
     torch.cuda.synchronize()
-    assert torch.equal(dsrc2, dsrc)
-    g = from_nhwc(dsrc2).double() * ((zp * bnp[0, 2][None, :, None, None] + bnp[0, 3][None, :, None, None]) > 0)
+    assert_masked('upsample bwd', from_nhwc(dsrc2), from_nhwc(dsrc), preact(zp, bnp, B))      # what is stored is g, the masked gradient
+    g = from_nhwc(dsrc2).double()
     got = part.cpu().double().sum(0)
     assert_close('upsample bwd: sum g', got[0], g.sum((0, 2, 3)), 2e-5 if prec == 'fp32' else 1e-4, 1e-4)
     assert_close('upsample bwd: sum g z', got[1], (g * zp.double()).sum((0, 2, 3)), 2e-5 if prec == 'fp32' else 1e-4, 1e-4)
@@ -404,9 +417,9 @@ def test_enc_skip_bwd(prec, case):
     _lib.call('bdn_enc_skip_bwd', dt, dF_d.data_ptr(), C + extra, z_d.data_ptr(), bn_d.data_ptr(),
               dP_d.data_ptr() if pooled else None, out2.data_ptr(), None, B, H, W, C, st())
     torch.cuda.synchronize()
-    assert torch.equal(out, out2)
+    assert_masked('enc_skip_bwd', from_nhwc(out), from_nhwc(out2), preact(z, bn, B))           # with the statistics the stored gradient is g (masked)
     # fused BatchNorm-backward partial sums: sum g and sum g*z over the STORED gradient, per date
-    g = from_nhwc(out).double() * (bnrelu_ref(prec, z, bn, B) > 0)
+    g = from_nhwc(out).double()
     for d in range(2):
         sl = slice(d * B, (d + 1) * B)
         got = part[d].double().sum(0).cpu()                       # [2][C]
@@ -544,8 +557,9 @@ def test_sgd_step():
 @pytest.mark.parametrize('case', [(4, 16, 16, 128, 64, 2), (6, 24, 40, 64, 128, 3), (4, 8, 8, 64, 64, 2), (2, 20, 18, 256, 128, 2),
                                   (2, 33, 17, 64, 64, 1), (8, 128, 128, 64, 64, 4)])
 def test_dgrad_with_fused_bn_bwd_stats(prec, case):
-    """bdn_conv3x3_dgrad_bs + bdn_bn_bwd_apply == bdn_conv3x3 (data gradient) + bdn_bn_bwd: identical dA, and
-    dgamma / dbeta / dz equal up to the summation order of the partial sums."""
+    """bdn_conv3x3_dgrad_bs + bdn_bn_bwd_apply == bdn_conv3x3 (data gradient) + bdn_bn_bwd: the stored dA is the plain data gradient
+    under the ReLU mask of the producing layer (identical where the mask is on), and dgamma / dbeta / dz equal up to the summation order
+    of the partial sums (BatchNorm backward applies the same mask again)."""
     N, H, W, Cz, Cout, ipg = case           # dz has Cz channels; the data gradient has Cout channels (= producing layer's width)
     dt, td = DT[prec]
     G = N // ipg
@@ -590,7 +604,7 @@ def test_dgrad_with_fused_bn_bwd_stats(prec, case):
               part.data_ptr(), nt // G, 1, sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dz.data_ptr(),
               scratch.data_ptr() if scratch is not None else None, st())
     torch.cuda.synchronize()
-    assert torch.equal(dA, dA_ref)
+    assert_masked('dgrad_bs', from_nhwc(dA), from_nhwc(dA_ref), preact(zprev, bn, ipg))       # identical where the ReLU is on, zero where it is off
     assert torch.isfinite(part).all()
     assert_close('dbeta', db.cpu(), db_r.cpu(), 2e-5)
     assert_close('dgamma', dg.cpu(), dg_r.cpu(), 2e-5, abs_floor=2e-4)

@@ -157,3 +157,30 @@ def test_two_chain_forward_is_bit_identical(prec, shape):
         assert len(got) == len(ref)
         for i, (a, r) in enumerate(zip(got, ref)):
             assert torch.equal(a, r), (chains, defer, levels, i)
+
+
+def test_bn_backward_folded_into_the_data_gradient_conv_matches_the_separate_pass():
+    """engine.fold_bn_bwd: for the listed 64-channel layers BatchNorm+ReLU backward is applied while the data-gradient conv stages its
+    operand (bdn_conv3x3_dgrad_bb, dz = a g + b z + c) instead of by the bdn_bn_bwd_apply pass.  Same mathematics, different rounding
+    points (bf16 dz differs by single steps in a few percent of the entries): loss identical, every gradient within 1 % relative L2 of
+    the unfolded step and the whole gradient vector at cosine >= 0.99999 (autograd of models/unet_parts.py:14-15,17-18)."""
+    c, b, s = 13, 4, 128
+    x1, x2, lbl = filler.make_inputs(b, c, s, seed=9)
+    x1, x2, lbl = torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), torch.from_numpy(lbl).cuda()
+
+    def run(fold):
+        model = filler.fill_module(BiDateNet(c, 2, precision='bf16')).cuda().train()
+        model.engine().fold_bn_bwd = fold
+        ts = TrainStep(model, lr=0.0)
+        loss = ts.step(x1, x2, lbl)
+        torch.cuda.synchronize()
+        return loss.item(), ts.flat_grads.clone(), {k: v.clone() for k, v in ts.grads.items()}
+
+    l0, g0, d0 = run(())
+    for fold in (('e1b',), ('e1b', 'd4a', 'd3a', 'd3b')):
+        l1, g1, d1 = run(fold)
+        assert l1 == l0
+        cos = float((g0.double() * g1.double()).sum() / (g0.double().norm() * g1.double().norm()))
+        worst = max(float((d1[k] - d0[k]).norm() / (d0[k].norm() + 1e-30)) for k in d0 if float(d0[k].norm()) > 1e-6)
+        print(f'fold {fold}: gradient cosine {cos:.7f}, worst per-parameter relative L2 {worst:.2e}')
+        assert cos >= 0.99999 and worst < 1e-2, (fold, cos, worst)

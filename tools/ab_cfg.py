@@ -1,6 +1,6 @@
 """In-process A/B of several engine configurations (test infrastructure):
     python tools/ab_cfg.py base: two:fwd_chains=2 two_nodefer:fwd_chains=2,defer_product=0 two_wg:fwd_chains=2,fwd_chain2_role=wgrad
-Each argument is  name:attr=value,attr=value  (engine attributes; ints are cast, anything else stays a string).  The configurations
+Each argument is  name:attr=value,attr=value  (engine attributes; ints are cast, fold_bn_bwd=e1b+d4a becomes a tuple, anything else stays a string).  The configurations
 are interleaved, 4 rounds x 20 steps each after 5 warm-up steps; prints the median ms/step of each and the ratio to the first."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ for a in sys.argv[1:]:
     kv = {}
     for item in filter(None, rest.split(',')):
         k, v = item.split('=')
-        kv[k] = int(v) if v.lstrip('-').isdigit() else v
+        kv[k] = int(v) if v.lstrip('-').isdigit() else (tuple(x for x in v.split('+') if x) if k == 'fold_bn_bwd' else v)
     cfgs.append((name, kv))
 B = int(os.environ.get('AB_BATCH', '64'))
 x1 = torch.randn(B, 13, 128, 128, device='cuda'); x2 = torch.randn(B, 13, 128, 128, device='cuda')
