@@ -585,7 +585,8 @@ static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 }
 
 // BatchNorm backward on load (bdn_conv3x3_dgrad_bb): the single-chunk shapes only (dz of a 64-channel layer) -- there the staging runs once,
-// in the prologue; inside the main loop of the multi-chunk kernels the second operand and the six per-channel constants spill.
+// in the prologue.  Inside the main loop of the two-chunk kernels the second operand (24 registers) and the three constants (24) do not fit:
+// 8x16x128 1x4 256 registers + 24 B of scratch, 16x16x64 4x1 256 + 308 B; the former was measured on e2b anyway (round 5): +0.5 % step time.
 static int dispatch_conv_bb(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
     if (g.TI != 1) BDN_FAIL(BDN_E_SHAPE, "conv3x3_dgrad_bb: maps of 8x8 and below are not supported");

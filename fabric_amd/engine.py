@@ -231,7 +231,8 @@ class BiDateEngine:
         # layers (64 output channels) whose BatchNorm backward is applied inside their data-gradient conv (bdn_conv3x3_dgrad_bb: dz = a g + b z + c
         # formed while the operand is staged) instead of by the bn_bwd_apply pass.  In-process A/B (tools/ab_cfg.py, round 5, three-constant
         # form on the masked gradient every fused producer stores): none +0.2 %, e1b = reference, e1b+d4a -0.2 %, +d3a -0.1 %, +d3b +0.1 %,
-        # all four +0.2 % -- everything within ~0.2 % of noise; the two full-resolution layers are kept (134 + 268 MB of dz reads less)
+        # all four +0.2 % -- everything within ~0.2 % of noise on that box; on a second box e1b alone is +0.6 % against e1b+d4a.
+        # The two full-resolution layers are kept (134 + 268 MB of dz reads less)
         self.fold_bn_bwd = ('e1b', 'd4a')
         # forward schedule (tools/archive/ab_flag.py).  fwd_chains = 2: the two dates go through encoder levels 1..fwd_chain_levels as two B-image chains on
         # two streams (the BatchNorm groups are per date already, so tables and bits do not change): one date's convolutions cover the
