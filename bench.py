@@ -115,9 +115,19 @@ def cpu_baseline(search_budget=30.0, confirm_budget=75.0):
     torch.set_num_threads(best_th)
     t16, n16 = timed(b16, 5, confirm_budget * 0.75)
     t4, n4 = timed(b4, 5, confirm_budget * 0.25)
+    # BASELINE configs[0] (the reference's own CPU-runnable case): BiDateNet(3, 2), 32 x 32 patches, batch 4
+    net, opt = O.build_torch_baseline(3, 2).train(), None
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    x1, x2, lbl = filler.make_inputs(4, 3, 32, seed=0)
+    c1 = (torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(lbl).long())
+    torch.set_num_threads(min(best_th, 8))              # a 1.4 GFLOP step: more threads only add synchronisation
+    tc1, nc1 = timed(c1, 5, 10.0)
+    torch.set_num_threads(best_th)
     listing = ', '.join(f'{th} threads: ' + (f'{16 / t:.2f} pairs/s ({n} steps)' if t is not None else 'skipped (budget / already slower with fewer threads)') for th, t, n in tried)
     return {'value': 16 / t16, 'unit': 'patch-pairs/s', 'cores': best_th, 'kind': 'port',
             'b4': {'value': 4 / t4, 'unit': 'patch-pairs/s', 'timed_steps': n4, 'ms_per_step': t4 * 1e3},
+            'config1': {'workload': 'BiDateNet(3,2) 32x32 patch pairs, batch 4 (BASELINE configs[0])', 'value': 4 / tc1, 'unit': 'patch-pairs/s',
+                        'timed_steps': nc1, 'ms_per_step': tc1 * 1e3, 'cores': min(best_th, 8)},
             'timed_steps': n16, 'ms_per_step': t16 * 1e3,
             'sample': f'13x128x128 fwd+Tversky+bwd+SGD steps, fp32 stock torch.nn assembly of the reference graph (oracle.build_torch_baseline, '
                       f'pinned to the golden logits by tests/test_oracle_cpu.py): median of {n16} timed steps at B=16 (value) and of {n4} at B=4 (b4) '
