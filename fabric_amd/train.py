@@ -136,6 +136,11 @@ def save_if_better(model, mean_val_metrics, best_metrics, metadata, epoch, out_d
     with open(os.path.join(out_dir, f'metadata_epoch_{epoch}.json'), 'w') as fout:
         json.dump(metadata, fout)
     torch.save(model, os.path.join(out_dir, f'checkpoint_epoch_{epoch}.pt'))
+    # ... and, for the way back, the parameters + BatchNorm buffers under the keys the REFERENCE's nn.DataParallel(BiDateNet) has
+    # (utils/helpers.py:335): the pickle above names fabric_amd's classes, which a reference checkout cannot import; this file loads there
+    # with model.load_state_dict(torch.load(path)) and here with fabric_amd.utils.helpers.load_checkpoint
+    torch.save({'module.' + k: v.detach().cpu() for k, v in model.state_dict().items()},
+               os.path.join(out_dir, f'checkpoint_epoch_{epoch}.state_dict.pt'))
     return mean_val_metrics
 
 
