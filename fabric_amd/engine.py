@@ -167,6 +167,11 @@ class Workspace:
         layer behind); 'a' the shared operand buffer of eval forwards; 'p' the weight-gradient GEMM's workspace on its stream."""
         t = self._split.get(which)
         if t is None or t.numel() < numel:
+            if t is not None:
+                # the buffer being replaced may still be read by a weight-gradient GEMM queued on the second stream: its block must not be
+                # handed out again before that stream has passed this point
+                from . import streams
+                t.record_stream(streams.get('wgrad', self.x0.device))
             t = torch.empty(numel, dtype=torch.bfloat16, device=self.x0.device)
             self._split[which] = t
         return t[:numel]
