@@ -645,7 +645,7 @@ def main():
                     help='N=1 only: the HEADLINE loop itself issues its gradient-bucket all-reduces through RCCL (world size 1)')
     ap.add_argument('--windows', type=int, default=3,
                     help='consecutive timed windows of --steps steps each; the headline is the MEDIAN window (all are reported)')
-    ap.add_argument('--engine-set', default='', help='A/B runs only: engine attributes for the headline loop, e.g. fwd_chains=1,defer_product=0')
+    ap.add_argument('--engine-set', default='', help='A/B runs only: engine attributes for the headline loop, e.g. fwd_chains=2,fwd_chain_levels=2')
     ap.add_argument('--launcher-selftest', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 

@@ -239,16 +239,10 @@ class BiDateEngine:
         # all four +0.2 % -- everything within ~0.2 % of noise on that box; on a second box e1b alone is +0.6 % against e1b+d4a.
         # The two full-resolution layers are kept (134 + 268 MB of dz reads less)
         self.fold_bn_bwd = ('e1b', 'd4a')
-        # forward schedule (tools/archive/ab_flag.py).  fwd_chains = 2: the two dates go through encoder levels 1..fwd_chain_levels as two B-image chains on
-        # two streams (the BatchNorm groups are per date already, so tables and bits do not change): one date's convolutions cover the
-        # other's statistics reductions / finalizes / pooling; the chains join where the skip product needs both dates.
-        # defer_product = 1: at the split levels each chain pools its own date (bdn_bnrelu_pool) and the skip products f_k run on the
-        # second stream beside encoder levels 4-5 (they are first read by the decoder); 0: products at the join, on the chain stream;
-        # 2: date 0's chain pools its own map, date 1's chain forms skip + its pooled map in one pass (bdn_product_pool_dates).
+        # forward schedule.  fwd_chains = 2: the two dates go through encoder levels 1..fwd_chain_levels as two B-image chains on two streams
+        # (_encoder_two_chains; bit-identical, measured +0.1...+1.3 % step time in round 5: off)
         self.fwd_chains = 1
         self.fwd_chain_levels = 3
-        self.defer_product = 1
-        self.fwd_chain2_role = 'chain2'
         self._fwd_handoffs = {}
         self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
@@ -459,9 +453,8 @@ class BiDateEngine:
             self._packed_valid = False
         rb = reuse_eval_bn and not training
         k_first = 1
-        deferred = None
         if self.fwd_chains == 2 and training and not self.x3:
-            k_first, deferred = self._encoder_two_chains(ws, P, by, st)
+            k_first = self._encoder_two_chains(ws, P, by, st)
         # ---- shared encoder on both dates (2B images, 2 statistic groups)
         for k in range(k_first, 6):
             hk, wk = ws.dims[k - 1]
@@ -493,9 +486,6 @@ class BiDateEngine:
             else:
                 call('bdn_upsample2x', self.dt, ptr(prev), prev_mode, ptr(prev_bn), ptr(ws.U[j]),
                      B, hs, wsrc, hk, wk, cprev, st)
-            if deferred is not None and k <= deferred[0]:
-                deferred[1].wait(torch.cuda.current_stream(dev))     # the skip products of the split levels were left on the second stream
-                deferred = None
             za, bna = self._conv(ws, La, P, None if pre else ws.f[k], ENC_CH[k - 1], None if pre else ws.U[j], cprev, IN_PLAIN, None, B, B,
                                  training, st, rb, presplit=pre)
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, training, st, rb)
@@ -515,16 +505,19 @@ class BiDateEngine:
 
     def _encoder_two_chains(self, ws, P, by, st):
         """Encoder levels 1..fwd_chain_levels with the two dates as two independent B-image chains: date 0 on the current (chain) stream,
-        date 1 on a second stream.  The reference runs the dates one after the other through the same modules (models/bidate_model.py:23-33);
-        here they were one 2B batch with two statistic groups -- the split changes no arithmetic (same tiles, same per-group reductions) but
-        lets one date's convolutions run while the other's dependent reduce / finalize / pool launches drain.  Ordering kept by events:
-        the running statistics and num_batches_tracked are updated by date 0's finalize first, then by date 1's (reference order).
-        Returns (first level the joined schedule continues with, deferred-product hand-off or None)."""
+        date 1 on the library's second stream (idle in forward).  The reference runs the dates one after the other through the same
+        modules (models/bidate_model.py:23-33); here they were one 2B batch with two statistic groups -- the split changes no arithmetic
+        (same tiles, same per-group reductions) but lets one date's convolutions run while the other's dependent reduce / finalize / pool
+        launches drain.  Ordering kept by events: the running statistics and num_batches_tracked are updated by date 0's finalize first,
+        then by date 1's (reference order).  Date 0's chain pools its own map; date 1's chain forms the skip f_k (it needs date 0's z and
+        table: ordered behind date 0's finalize of that layer already) together with ITS pooled map in one pass.  Measured (round 5, six
+        more variants of where the products run / which stream / how many levels): +0.1...+1.3 % step time -- the option stays OFF.
+        Returns the first level the joined schedule continues with."""
         from . import streams
         B = ws.B
         dev = ws.x0.device
         main = torch.cuda.current_stream(dev)
-        second = streams.get(self.fwd_chain2_role, dev)
+        second = streams.get('wgrad', dev)
         Lmax = max(1, min(4, self.fwd_chain_levels))
         ev = [0]
 
@@ -552,42 +545,15 @@ class BiDateEngine:
                         return dict(before_finalize=lambda: fin_events[L.name].wait(stream))
                     za, bna = self._conv(ws, La, P, src[d * B:(d + 1) * B], La.cin, None, 0, IN_PLAIN, None, B, B, True, sp, date=d, **order(La))
                     zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, B, B, True, sp, date=d, **order(Lb))
-                    if self.defer_product == 2:
-                        # date 0's chain pools its own map and runs on; date 1's chain forms the skip (it needs date 0's z and table: ordered
-                        # behind date 0's finalize of this layer already) together with ITS pooled map in one pass
-                        if d == 0:
-                            call('bdn_bnrelu_pool', self.dt, ptr(zb), ptr(bnb), B, ptr(ws.pool[k + 1][:B]), B, hk, wk, ENC_CH[k - 1], sp)
-                        else:
-                            call('bdn_product_pool_dates', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[k]), ptr(ws.pool[k + 1]), 2,
-                                 B, hk, wk, ENC_CH[k - 1], sp)
-                    elif self.defer_product or k < Lmax:
-                        # each chain pools its own date; the skip product follows off the critical path (or at the join)
-                        call('bdn_bnrelu_pool', self.dt, ptr(zb), ptr(bnb), B, ptr(ws.pool[k + 1][d * B:(d + 1) * B]), B, hk, wk, ENC_CH[k - 1], sp)
+                    if d == 0:
+                        call('bdn_bnrelu_pool', self.dt, ptr(zb), ptr(bnb), B, ptr(ws.pool[k + 1][:B]), B, hk, wk, ENC_CH[k - 1], sp)
+                    else:
+                        call('bdn_product_pool_dates', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[k]), ptr(ws.pool[k + 1]), 2,
+                             B, hk, wk, ENC_CH[k - 1], sp)
         join = new_ev()
         join.signal(second)
         join.wait(main)
-        if self.defer_product == 2:
-            return Lmax + 1, None
-        # ---- skip products of the split levels: need both dates
-        def products(sp, levels):
-            for k in levels:
-                hk, wk = ws.dims[k - 1]
-                Lb = by[f'e{k}b']
-                call('bdn_fuse_product', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[k]), B, hk, wk, ENC_CH[k - 1], sp)
-        if self.defer_product:
-            back = new_ev()
-            back.signal(main)                                # date 0's z of the last split level
-            back.wait(second)
-            with torch.cuda.stream(second):
-                products(second.cuda_stream, range(Lmax, 0, -1))     # the decoder needs f_Lmax first
-            done = new_ev()
-            done.signal(second)
-            return Lmax + 1, (Lmax, done)
-        hk, wk = ws.dims[Lmax - 1]
-        Lb = by[f'e{Lmax}b']
-        call('bdn_product_pool', self.dt, ptr(ws.z[Lb.name]), ptr(ws.bn[Lb.name]), ptr(ws.f[Lmax]), ptr(ws.pool[Lmax + 1]), B, hk, wk, ENC_CH[Lmax - 1], st)
-        products(st, range(Lmax - 1, 0, -1))
-        return Lmax + 1, None
+        return Lmax + 1
 
     # ------------------------------------------------------------------ backward
     def backward(self, ws, dlogits, P, grads, on_ready=None, zero_bias_grads=True, wgrad_stream=True):

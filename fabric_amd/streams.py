@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 
-_ROLES = {'chain': 1, 'wgrad': 0, 'copy': 0, 'copy2': 0, 'chain2': 1}        # role -> bdn_stream_create priority
+_ROLES = {'chain': 1, 'wgrad': 0, 'copy': 0, 'copy2': 0}        # role -> bdn_stream_create priority
 _streams = {}
 _lock = threading.Lock()
 

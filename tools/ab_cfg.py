@@ -1,5 +1,5 @@
 """In-process A/B of several engine configurations (test infrastructure):
-    python tools/ab_cfg.py base: two:fwd_chains=2 two_nodefer:fwd_chains=2,defer_product=0 two_wg:fwd_chains=2,fwd_chain2_role=wgrad
+    python tools/ab_cfg.py base: two:fwd_chains=2 two_l2:fwd_chains=2,fwd_chain_levels=2 fold:fold_bn_bwd=e1b+d4a+d3a
 Each argument is  name:attr=value,attr=value  (engine attributes; ints are cast, fold_bn_bwd=e1b+d4a becomes a tuple, anything else stays a string).  The configurations
 are interleaved, 4 rounds x 20 steps each after 5 warm-up steps; prints the median ms/step of each and the ratio to the first."""
 import os, sys, statistics
