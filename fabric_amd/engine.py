@@ -261,8 +261,10 @@ class BiDateEngine:
         """Symbol of the conv3x3_kernel instantiation bdn_conv3x3 dispatches to: asked from the library's own dispatcher."""
         return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg).decode()
 
-    def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3'):
+    def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3', bb=False):
         name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
+        if name is not None and bb:                 # BatchNorm-backward-on-load launches: the same tile configuration, template flag BB set
+            name = name[:name.rindex(',')] + ',true>'
         if self.prof is None or (self.prof_filter is not None and name not in self.prof_filter):
             call(fn, *args)
             return
@@ -613,9 +615,10 @@ class BiDateEngine:
             _, wd = self._weights(L, P, True)
             dz, out = e(n, hk, wk, L.cout), e(n, hk, wk, L.cin)
             has = prev is not None
-            call('bdn_conv3x3_dgrad_bb', self.mdt, dA, L.cout, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ptr(sc['sums']), ipg, ptr(wd), ptr(out),
-                 ptr(ws.z[prev.name]) if has else None, ptr(ws.bn[prev.name]) if has else None, ptr(ws.stats) if has else None,
-                 ptr(dz), n, hk, wk, L.cin, st)
+            self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
+                             self.mdt, dA, L.cout, ptr(ws.z[L.name]), ptr(ws.bn[L.name]), ptr(sc['sums']), ipg, ptr(wd), ptr(out),
+                             ptr(ws.z[prev.name]) if has else None, ptr(ws.bn[prev.name]) if has else None, ptr(ws.stats) if has else None,
+                             ptr(dz), n, hk, wk, L.cin, st, fn='bdn_conv3x3_dgrad_bb', bb=True)
             if has:
                 return dz, out, _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // G
             return dz, out

@@ -43,6 +43,24 @@ def get_criterion(opt):
                               f'branch fails on [B,2,H,W] logits vs [B,H,W] labels and is not built')
 
 
+def get_loaders(opt):
+    """reference utils/helpers.py:211-258, same signature and return value: (train_loader, val_loader) over OneraPreloader datasets
+    built from `opt.dataset_dir` (OSCD layout), `opt.validation_cities`, `opt.patch_size`, `opt.stride`, `opt.augmentation`,
+    `opt.batch_size`, `opt.num_workers` (+ `opt.band_ids / band_means / band_stds` for the ingest).  One process, no sharding: this is
+    the reference's loader for the reference's loop; the data-parallel loop of fabric_amd.train uses make_loaders (per-rank shards)."""
+    from . import ingest
+    from .dataloaders import OneraPreloader
+    train_samples, val_samples = ingest.get_train_val_metadata(opt.dataset_dir, opt.validation_cities, opt.patch_size, opt.stride)
+    print('train samples : ', len(train_samples))
+    print('val samples : ', len(val_samples))
+    full_load = ingest.full_onera_loader(opt.dataset_dir, opt)
+    train_dataset = OneraPreloader(opt.dataset_dir, train_samples, full_load, opt.patch_size, opt.augmentation)
+    val_dataset = OneraPreloader(opt.dataset_dir, val_samples, full_load, opt.patch_size, False)
+    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=opt.batch_size, shuffle=True, num_workers=opt.num_workers)
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=opt.batch_size, shuffle=False, num_workers=opt.num_workers)
+    return train_loader, val_loader
+
+
 def load_model(opt, device, precision=None):
     """reference utils/helpers.py:317-337 builds nn.DataParallel(BiDateNet(13, 2)); here one process drives one
     GPU and gradients are exchanged by fabric_amd.parallel (RCCL), so the bare module is returned."""

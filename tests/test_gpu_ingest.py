@@ -93,6 +93,18 @@ def test_full_onera_loader_and_generate_patches(tmp_path):
     # the reference's dataloaders names resolve to the ingest module
     from fabric_amd.utils import dataloaders as dl
     assert dl.city_loader is ing.city_loader and dl.get_train_val_metadata is ing.get_train_val_metadata
+    # the reference's get_loaders(opt) (utils/helpers.py:211-258), same signature: DataLoaders over the ingested cities
+    from fabric_amd.utils.helpers import get_loaders
+    opt.dataset_dir, opt.validation_cities, opt.patch_size, opt.stride = root, ['beta'], 16, 16
+    opt.augmentation, opt.batch_size, opt.num_workers = False, 3, 0
+    tr, va = get_loaders(opt)
+    tm, vm = ing.get_train_val_metadata(root, ['beta'], 16, 16)
+    assert len(tr.dataset) == len(tm) and len(va.dataset) == len(vm) and len(vm) > 0
+    b1, b2, lb = next(iter(va))
+    c0, i0, j0 = va.dataset.imgs[0]               # OneraPreloader shuffles its index list in place (utils/dataloaders.py:171)
+    assert b1.shape[1:] == (13, 16, 16) and lb.dtype == torch.uint8
+    assert np.array_equal(b1[0].numpy(), ds[c0]['images'][0][:, i0:i0 + 16, j0:j0 + 16])
+    assert np.array_equal(lb[0].numpy(), ds[c0]['labels'][i0:i0 + 16, j0:j0 + 16])
 
 
 def test_train_loop_on_an_oscd_directory(tmp_path, capsys):
