@@ -632,10 +632,11 @@ class BiDateEngine:
                 # (per-layer buffers: the weight-gradient stream may still read one while the chain splits the next layer's)
                 sd = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)
                 sw = ws.split_buf(('a', L.name), n * hk * wk * 2 * (c0 + c1))
-                nb = lib.bdn_wgrad_workspace_bytes_ex(BDN_BF16X3, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, 3)
+                flg = wg_flags(3, 0, self.wgrad_blocks)
+                nb = lib.bdn_wgrad_workspace_bytes_ex(BDN_BF16X3, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, flg)
                 part = ws.split_buf('p', nb // 2)
                 call('bdn_conv3x3_wgrad_ex', BDN_BF16X3, ptr(sd), L.cout, ptr(sw), c0 + c1, None, 0, IN_PLAIN, None, ipg,
-                     ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, 3, stp)
+                     ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, flg, stp)
                 return
             wk_, blk_ = self.wgrad_kernel, self.wgrad_blocks
             args = (self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
