@@ -195,52 +195,82 @@ constexpr int OUTC_BWD_ITERS = 32;  // ... and backward: every block ends with 1
 // NC = compile-time class-count bound (2 for the change / no-change head, 8 generic): loops over classes unroll
 // without runtime predicates.  CU = C/EPU consecutive lanes share one pixel (each reads 16 contiguous bytes ->
 // fully coalesced), partial dot products are combined with xor-shuffles inside the CU-lane group.
-template <typename T, int NC>
-__global__ void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ w,
+// CUC: the lanes per pixel as a compile-time constant (8 or 16: the 64-channel head in bf16 / float32), 0 = run-time.  With it the
+// partial dot products of a pixel meet in its first lane by DPP row shifts (same association as the xor butterfly: 4, 2, 1 -- the
+// same bits) instead of ds_bpermute round trips in a run-time loop, and the next four pixels of a lane are requested before the
+// current four are reduced (round 5: 42 -> 3x us at B = 64).
+template <int N> __device__ __forceinline__ float dpp_row_shl(float v) {     // lane i <- lane i + N of its row of 16 (0 beyond the row)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+template <int CU> __device__ __forceinline__ float first_lane_sum(float v) {
+    static_assert(CU == 8 || CU == 16, "lanes per pixel");
+    if constexpr (CU == 16) v += dpp_row_shl<8>(v);
+    v += dpp_row_shl<4>(v); v += dpp_row_shl<2>(v); v += dpp_row_shl<1>(v);
+    return v;
+}
+template <typename T, int NC, int CUC = 0>
+__global__ __launch_bounds__(256) void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ w,
                                 const float* __restrict__ bias, float* __restrict__ logits, int npix, int hw, int C, int ncls, FastDiv dhw) {
     constexpr int EPU = ET<T>::EPU;
-    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
-    float sc[EPU], sh[EPU], wk[NC][EPU];
+    const int CU = CUC ? CUC : C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    float sc[EPU], sh[EPU], wk[NC][EPU], bk[NC];
 #pragma unroll
     for (int i = 0; i < EPU; i++) { sc[i] = bn_row(bn, 0, 2, C)[c + i]; sh[i] = bn_row(bn, 0, 3, C)[c + i]; }
 #pragma unroll
-    for (int k = 0; k < NC; k++)
+    for (int k = 0; k < NC; k++) {
+        const int kk = k < ncls ? k : 0;                                           // unconditional loads, selected afterwards
+        const float bv = bias[kk];
+        bk[k] = k < ncls ? bv : 0.f;
 #pragma unroll
-        for (int i = 0; i < EPU; i++) wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f;
-    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_ITERS);
-    // four pixels of a lane are requested before the first is used: with one 16-byte load in flight per lane the pass ran at 3.6 TB/s
-    for (int p0 = blockIdx.x * rows * OUTC_ITERS; p0 < p_end; p0 += 4 * rows) {   // block-uniform trip count
-        uint4 u[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int p = p0 + j * rows + row;
-            u[j] = *reinterpret_cast<const uint4*>(z + (size_t)(p < p_end ? p : p0) * C + c);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int p = p0 + j * rows + row;
-            if (p0 + j * rows >= p_end) break;                                    // block-uniform
-            float f[EPU], acc[NC];
-#pragma unroll
-            for (int k = 0; k < NC; k++) acc[k] = 0.f;
-            if (p < p_end) {
-                Unit<T>::unpack(u[j], f);
-#pragma unroll
-                for (int i = 0; i < EPU; i++) {
-                    const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
-#pragma unroll
-                    for (int k = 0; k < NC; k++) acc[k] = fmaf(a, wk[k][i], acc[k]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NC; k++)
-                for (int off = CU >> 1; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
-            if (cu == 0 && p < p_end) {
-                int b, q; dhw.divmod(p, b, q);
-                for (int k = 0; k < ncls; k++) logits[((size_t)b * ncls + k) * hw + q] = acc[k] + bias[k];
-            }
-        }
+        for (int i = 0; i < EPU; i++) { const float wv = w[kk * C + c + i]; wk[k][i] = k < ncls ? wv : 0.f; }
     }
+    const int p_begin = blockIdx.x * rows * OUTC_ITERS, p_end = min(npix, p_begin + rows * OUTC_ITERS);
+    // four pixels of a lane are requested before the first is used (with one 16-byte load in flight per lane the pass ran at 3.6 TB/s),
+    // and the following four before these are reduced.  RAGGED_ = false: the block's whole range lies inside the tensor (every block
+    // but possibly the last) -- no per-pixel bounds tests
+    uint4 u[4], un[4];
+#define OUTC_LOAD4(dst_, p0_, RAGGED_)                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                      \
+        const int p_ = (p0_) + j * rows + row;                                                          \
+        dst_[j] = *reinterpret_cast<const uint4*>(z + (size_t)(!(RAGGED_) || p_ < p_end ? p_ : (p0_)) * C + c); \
+    }
+#define OUTC_RUN(RAGGED_)                                                                                \
+    {                                                                                                   \
+        OUTC_LOAD4(u, p_begin, RAGGED_)                                                                 \
+        for (int p0 = p_begin; p0 < p_end; p0 += 4 * rows) {                      /* block-uniform trip count */ \
+            const bool more = p0 + 4 * rows < p_end;                                                    \
+            /* unconditional (the last trip re-requests its own pixels): a branch here makes the compiler wait for ALL loads, */ \
+            /* the new ones included, before the first use of the current four */                        \
+            { const int pn_ = more ? p0 + 4 * rows : p0; OUTC_LOAD4(un, pn_, RAGGED_) }                  \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {                                              \
+                const int p = p0 + j * rows + row;                                                      \
+                if ((RAGGED_) && p0 + j * rows >= p_end) break;                   /* block-uniform */   \
+                const bool in_ = !(RAGGED_) || p < p_end;                                               \
+                float f[EPU], acc[NC];                                                                  \
+                _Pragma("unroll") for (int k = 0; k < NC; k++) acc[k] = 0.f;                             \
+                Unit<T>::unpack(u[j], f);                                                               \
+                _Pragma("unroll") for (int i = 0; i < EPU; i++) {                                        \
+                    const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));              \
+                    _Pragma("unroll") for (int k = 0; k < NC; k++) acc[k] = fmaf(a, wk[k][i], acc[k]);   \
+                }                                                                                       \
+                if constexpr (CUC != 0) {                                                               \
+                    _Pragma("unroll") for (int k = 0; k < NC; k++) acc[k] = first_lane_sum<CUC ? CUC : 8>(acc[k]); \
+                } else {                                                                                \
+                    _Pragma("unroll") for (int k = 0; k < NC; k++)                                       \
+                        for (int off = CU >> 1; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);  \
+                }                                                                                       \
+                if (cu == 0 && in_) {                                                                   \
+                    int b, q; dhw.divmod(p, b, q);                                                      \
+                    _Pragma("unroll") for (int k = 0; k < NC; k++) if (k < ncls) logits[((size_t)b * ncls + k) * hw + q] = acc[k] + bk[k]; \
+                }                                                                                       \
+            }                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) u[j] = un[j];                                  \
+        }                                                                                               \
+    }
+    if (p_begin >= p_end) return;
+    if (p_begin + rows * OUTC_ITERS <= npix) OUTC_RUN(false) else OUTC_RUN(true)
+#undef OUTC_RUN
+#undef OUTC_LOAD4
 }
 
 extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const float* w, const float* b,
@@ -250,11 +280,13 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
     hipStream_t st = (hipStream_t)stream; const int npix = B * H * W, hw = H * W;
     if (dtype == BDN_BF16) {
         const int per = 256 / (C / 8) * OUTC_ITERS; const unsigned grid = (npix + per - 1) / per;
-        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<bf16s, 2>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
+        if (ncls <= 2 && C == 64) hipLaunchKernelGGL((outc_fwd_kernel<bf16s, 2, 8>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
+        else if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<bf16s, 2>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
         else hipLaunchKernelGGL((outc_fwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const bf16s*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
     } else if (dtype == BDN_F32) {
         const int per = 256 / (C / 4) * OUTC_ITERS; const unsigned grid = (npix + per - 1) / per;
-        if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
+        if (ncls <= 2 && C == 64) hipLaunchKernelGGL((outc_fwd_kernel<float, 2, 16>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
+        else if (ncls <= 2) hipLaunchKernelGGL((outc_fwd_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
         else hipLaunchKernelGGL((outc_fwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), 0, st, (const float*)z, bn, w, b, logits, npix, hw, C, ncls, FastDiv(hw));
     }
     else BDN_FAIL(BDN_E_ARG, "outc_fwd: bad dtype");
@@ -266,13 +298,13 @@ extern "C" int bdn_outc_fwd(int dtype, const void* z, const float* bn, const flo
 // Thread t owns channel unit t % CU (its filter taps, BN constants and dw accumulators live in registers)
 // and walks pixels t / CU, +rows, ...; the block partials of dw/db go to a workspace and are summed in a fixed order by
 // outc_dw_reduce_kernel (the first version added them with float atomics: the only non-deterministic bits of a step).
-template <typename T, int NC>
+template <typename T, int NC, int CUC = 0>          // CUC: lanes per pixel at compile time (see outc_fwd_kernel), 0 = run-time
 __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ z, const float* __restrict__ bn,
                                 const float* __restrict__ w, T* __restrict__ dA, float* __restrict__ wpart,
                                 float* __restrict__ bs_partial, int npix, int hw, int C, int ncls, FastDiv dhw) {
     constexpr int EPU = ET<T>::EPU;
     extern __shared__ float sm[];                             // [ncls][C+1] block sums + [256][EPU][2] reduction scratch
-    const int CU = C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
+    const int CU = CUC ? CUC : C / EPU, rows = 256 / CU, tid = threadIdx.x, cu = tid % CU, row = tid / CU, c = cu * EPU;
     for (int i = tid; i < ncls * (C + 1); i += 256) sm[i] = 0.f;
     float sc[EPU], sh[EPU], wk[NC][EPU], acc[NC][EPU], accb[NC], t0[EPU], t1[EPU];
 #pragma unroll
@@ -281,54 +313,68 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         accb[k] = 0.f;
+        const int kk = k < ncls ? k : 0;
 #pragma unroll
-        for (int i = 0; i < EPU; i++) { wk[k][i] = k < ncls ? w[k * C + c + i] : 0.f; acc[k][i] = 0.f; }
+        for (int i = 0; i < EPU; i++) { const float wv = w[kk * C + c + i]; wk[k][i] = k < ncls ? wv : 0.f; acc[k][i] = 0.f; }
     }
     __syncthreads();
-    const int p_end = min(npix, (int)(blockIdx.x + 1) * rows * OUTC_BWD_ITERS);
-    for (int pb = blockIdx.x * rows * OUTC_BWD_ITERS + row; pb < p_end; pb += 4 * rows) {
-        // four pixels of a lane are requested before the first is used; they are still accumulated one after the other, in order
-        uint4 zu[4]; float gv[4][NC];
+    const int p_begin = blockIdx.x * rows * OUTC_BWD_ITERS, p_end = min(npix, p_begin + rows * OUTC_BWD_ITERS);
+    // four pixels of a lane are requested before the first is used, and the following four before these are consumed (unconditionally:
+    // the last trip re-requests its own -- a branch around the requests makes the compiler drain them all before the first use); the
+    // pixels are still accumulated one after the other, in order
+    uint4 zu[4], zn[4]; float gv[4][NC], gn[4][NC];
+#define OUTC_BLOAD4(zd_, gd_, p0_)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                      \
+        const int pj_ = (p0_) + j * rows + row < p_end ? (p0_) + j * rows + row : p_begin + row;          \
+        int b_, q_; dhw.divmod(pj_, b_, q_);                                                            \
+        _Pragma("unroll") for (int k = 0; k < NC; k++) gd_[j][k] = dl[((size_t)b_ * ncls + (k < ncls ? k : 0)) * hw + q_]; \
+        zd_[j] = *reinterpret_cast<const uint4*>(z + (size_t)pj_ * C + c);                              \
+    }
+    if (p_begin + row < p_end) {                              // (a block's first row of pixels is inside the tensor whenever the block has work)
+        OUTC_BLOAD4(zu, gv, p_begin)
+        for (int p0 = p_begin; p0 < p_end; p0 += 4 * rows) {  // block-uniform trip count
+            { const int pn_ = p0 + 4 * rows < p_end ? p0 + 4 * rows : p0; OUTC_BLOAD4(zn, gn, pn_) }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int pj = pb + j * rows < p_end ? pb + j * rows : pb;
-            int b, q; dhw.divmod(pj, b, q);
+            for (int j = 0; j < 4; j++) {
+                const int p = p0 + j * rows + row;
+                if (p < p_end) {
+                    float g[NC], f[EPU], o[EPU];
 #pragma unroll
-            for (int k = 0; k < NC; k++) gv[j][k] = k < ncls ? dl[((size_t)b * ncls + k) * hw + q] : 0.f;
-            zu[j] = *reinterpret_cast<const uint4*>(z + (size_t)pj * C + c);
-        }
+                    for (int k = 0; k < NC; k++) g[k] = k < ncls ? gv[j][k] : 0.f;
+                    Unit<T>::unpack(zu[j], f);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int p = pb + j * rows;
-            if (p >= p_end) break;
-            float g[NC], f[EPU], o[EPU];
+                    for (int i = 0; i < EPU; i++) {
+                        const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
+                        float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < NC; k++) g[k] = gv[j][k];
-            Unit<T>::unpack(zu[j], f);
+                        for (int k = 0; k < NC; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
+                        o[i] = s;
+                    }
+                    if (cu == 0) {
 #pragma unroll
-            for (int i = 0; i < EPU; i++) {
-                const float a = to_f(from_f<T>(fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f)));
-                float s = 0.f;
+                        for (int k = 0; k < NC; k++) accb[k] += g[k];
+                    }
+                    const uint4 uo = Unit<T>::pack(o);
+                    if (dA) *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
+                    if (bs) {                                             // BatchNorm-backward partial sums of this layer on the stored gradient
+                        Unit<T>::unpack(uo, o);
 #pragma unroll
-                for (int k = 0; k < NC; k++) if (k < ncls) { s = fmaf(g[k], wk[k][i], s); acc[k][i] = fmaf(g[k], a, acc[k][i]); }
-                o[i] = s;
-            }
-            if (cu == 0) {
-#pragma unroll
-                for (int k = 0; k < NC; k++) accb[k] += g[k];
-            }
-            const uint4 uo = Unit<T>::pack(o);
-            if (dA) *reinterpret_cast<uint4*>(dA + (size_t)p * C + c) = uo;
-            if (bs) {                                             // BatchNorm-backward partial sums of this layer on the stored gradient
-                Unit<T>::unpack(uo, o);
-#pragma unroll
-                for (int i = 0; i < EPU; i++) {
-                    const float gm = fmaf(f[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
-                    t0[i] += gm; t1[i] = fmaf(gm, f[i], t1[i]);
+                        for (int i = 0; i < EPU; i++) {
+                            const float gm = fmaf(f[i], sc[i], sh[i]) > 0.f ? o[i] : 0.f;
+                            t0[i] += gm; t1[i] = fmaf(gm, f[i], t1[i]);
+                        }
+                    }
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                zu[j] = zn[j];
+#pragma unroll
+                for (int k = 0; k < NC; k++) gv[j][k] = gn[j][k];
             }
         }
     }
+#undef OUTC_BLOAD4
     // block sums of dw / db in a fixed order: per class every thread parks its partials in LDS, then one thread per
     // channel adds the block's `rows` pixel rows in order (LDS atomics would make the last bits depend on wave timing)
     {
@@ -408,10 +454,12 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
     const unsigned grid = bdn_outc_bwd_rows(dtype, B, H, W, C);
     const size_t smem = sizeof(float) * (ncls * (C + 1) + 256 * (dtype == BDN_BF16 ? 8 : 4) * 2);
     if (dtype == BDN_BF16) {
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
+        if (ncls <= 2 && C == 64) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2, 8>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
+        else if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<bf16s, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
         else hipLaunchKernelGGL((outc_bwd_kernel<bf16s, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const bf16s*)z, bn, w, (bf16s*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
     } else if (dtype == BDN_F32) {
-        if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
+        if (ncls <= 2 && C == 64) hipLaunchKernelGGL((outc_bwd_kernel<float, 2, 16>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
+        else if (ncls <= 2) hipLaunchKernelGGL((outc_bwd_kernel<float, 2>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
         else hipLaunchKernelGGL((outc_bwd_kernel<float, OUTC_MAXCLS>), dim3(grid), dim3(256), smem, st, dlogits, (const float*)z, bn, w, (float*)dA, ws, bs_partial, npix, H * W, C, ncls, FastDiv(H * W));
     } else BDN_FAIL(BDN_E_ARG, "outc_bwd: bad dtype");
     BDN_CHECK_LAUNCH("outc_bwd");
