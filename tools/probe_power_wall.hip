@@ -12,6 +12,10 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// SHARED = false: both source registers change between consecutive MFMAs.  SHARED = true: srcB is shared by four consecutive MFMAs and srcA
+// changes -- the order of the convolutions' 1x4 wave tile (tools/probe_operand_reuse.hip has the other orders: a change of srcA costs ~4x
+// a change of srcB, so the ceiling depends on the walk)
+template <bool SHARED>
 __global__ void __launch_bounds__(256, 1) k(const uint4* __restrict__ ops, float* out, int iters) {
     f32x16 acc[4];
     for (int t = 0; t < 4; t++) for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
@@ -23,7 +27,8 @@ __global__ void __launch_bounds__(256, 1) k(const uint4* __restrict__ ops, float
         for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(t + u) & 3]), __builtin_bit_cast(bf16x8, f[4 + ((t + 2 * u) & 3)]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[SHARED ? t : (t + u) & 3]),
+                                                                 __builtin_bit_cast(bf16x8, f[4 + (SHARED ? u : (t + 2 * u) & 3)]), acc[t], 0, 0, 0);
     }
     float r = 0.f;
     for (int t = 0; t < 4; t++) for (int q = 0; q < 16; q++) r += acc[t][q];
@@ -38,23 +43,24 @@ int main() {
     uint16_t* h = (uint16_t*)malloc(n * 2);
     uint4* d; float* out;
     hipMalloc(&d, n * 2); hipMalloc(&out, blocks * 256 * 4);
-    const char* names[] = {"all zero", "all 1.0", "N(0,1) random", "N(0,1), half of the A values zero (ReLU-like)"};
-    for (int mode = 0; mode < 4; mode++) {
+    const char* names[] = {"all zero", "all 1.0", "N(0,1) random", "N(0,1), half of the A values zero (ReLU-like)", "N(0,1) random, srcB shared by 4 MFMAs (1x4 tile)"};
+    for (int mode = 0; mode < 5; mode++) {
         uint64_t s = 88172645463325252ull;
         for (int i = 0; i < n; i++) {
             s ^= s << 13; s ^= s >> 7; s ^= s << 17;
             float u1 = ((s >> 11) & 0xffffff) / 16777216.f + 1e-7f, u2 = ((s >> 35) & 0xffffff) / 16777216.f;
             float g = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
-            float v = mode == 0 ? 0.f : mode == 1 ? 1.f : g;
+            float v = mode == 0 ? 0.f : mode == 1 ? 1.f : g;                            // mode 4: random data, the other kernel
             if (mode == 3 && ((i / 8 / 256) % 8) < 4 && g < 0.f) v = 0.f;        // the four A fragments: relu
             h[i] = bf16_of(v);
         }
         hipMemcpy(d, h, n * 2, hipMemcpyHostToDevice);
         const int iters = 40000;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, out, 2000);
+        auto kern = mode == 4 ? k<true> : k<false>;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, out, 2000);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, out, iters);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, out, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double mfma = (double)iters * 16 * 4 * blocks;                        // MFMA instructions (4 waves per block)
