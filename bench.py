@@ -247,10 +247,11 @@ def mfma_ceiling():
         return {'unit': 'TFLOP/s', 'zero_operands': rows.get('all zero'), 'random_operands': rnd,
                 'random_operands_srcB_shared_by_4': rows.get('N(0,1) random, srcB shared by 4 MFMAs (1x4 tile)'),
                 'frac_of_nominal_peak': None if rnd is None else rnd / (MFMA_BF16_PEAK / 1e12),
-                'how': 'bare v_mfma_f32_32x32x16_bf16 loop, one wave per SIMD on every CU, operands in registers (tools/probe_power_wall.hip): '
-                       'the chip clocks to its power budget; random_operands = both source registers change every MFMA, '
-                       'random_operands_srcB_shared_by_4 = the order of the convolutions\' 1x4 wave tile (a change of srcA costs ~4x a change '
-                       'of srcB: profiles/r5_operand_reuse.txt)'}
+                'how': 'bare v_mfma_f32_32x32x16_bf16 loop, one wave per SIMD on every CU, operands in registers, each row after three whole '
+                       'warm-up launches (tools/probe_power_wall.hip): the chip clocks to its power budget; random_operands = both source '
+                       'registers change every MFMA, random_operands_srcB_shared_by_4 = the order of the convolutions\' 1x4 wave tile (the '
+                       'order moves the ceiling by 0...3 % only; rounds 3-4 quoted 1.53-1.61 PFLOP/s here from inside the clock ramp that '
+                       'follows the host-side data fill: profiles/r5_operand_reuse.txt)'}
     except Exception as e:
         return {'error': f'{type(e).__name__}: {e}'}
 

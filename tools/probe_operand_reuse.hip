@@ -2,6 +2,7 @@
 // The bare loop of probe_power_wall changes BOTH operands between consecutive MFMAs.  A convolution's wave tile does not: in the 1x4
 // layout four consecutive MFMAs share their filter fragment, in a 2x2 layout the order of the four (pixel, channel) pairs is free.
 // If the matrix core's input toggling matters, operand-stationary orders should clock higher on random data.
+// Answer (profiles/r5_operand_reuse.txt): barely -- +0 % for the 1x4 / 4x1 orders, +1.3 % for 2x2, +2.8 % when nothing changes.
 //   hipcc --offload-arch=gfx950 -O3 tools/probe_operand_reuse.hip -o tools/probe_operand_reuse && tools/probe_operand_reuse
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -65,7 +66,10 @@ static uint16_t bf16_of(float v) { uint32_t u; memcpy(&u, &v, 4); return (uint16
 template <typename K>
 static void run(const char* name, K kern, const uint4* d, float* out, int blocks, double flop_per_inst, int inst_per_iter) {
     const int iters = 30000;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, out, 2000);
+    // warm-up = the whole timed launch twice: the first tens of ms after a host-side pause run 5-12 % slower (clock ramp), which a short
+    // warm-up does not cover -- it made the first row of every data block look like an order effect in the first version of this probe
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, out, iters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, out, iters);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, out, iters);
@@ -105,6 +109,7 @@ int main() {
         run("32x32x16, 2x2 tile row-major", k32<4>, d, out, blocks, f32, 16);
         run("32x32x16, one A and one B throughout", k32<2>, d, out, blocks, f32, 16);
         run("16x16x32, both operands change", k16, d, out, blocks, f16, 32);
+        run("32x32x16, both operands change every MFMA (again, last)", k32<0>, d, out, blocks, f32, 16);
     }
     return 0;
 }
