@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256 * WAVES, 1) k(const uint4* __restrict__ op
 
 // the same feed with DEEP prefetch: filter fragments three groups ahead (ring of four), pixel fragments two groups ahead (three sets) --
 // if the rows above were latency-bound this one is faster; if it is not, what limits them is not latency
-template <int LDS, int WAVES>
+template <int LDS, int WAVES, bool BLDS = false>
 __global__ void __launch_bounds__(256 * WAVES, 1) kdeep(const uint4* __restrict__ ops, const uint4* __restrict__ filt, float* out, int iters) {
     extern __shared__ uint4 sm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256 * WAVES, 1) kdeep(const uint4* __restrict_
     {                                                                                                   \
         off += 256; fo = fo + 64 >= 9216 ? 0 : fo + 64;                                                 \
         _Pragma("unroll") for (int i = 0; i < LDS; i++) AN[i] = sm[(off + i * 64 + lane) & 4095];        \
-        BN = filt[fo + lane];                                                                           \
+        if (BLDS) BN = sm[(off + 2048 + lane) & 4095]; else BN = filt[fo + lane];                       \
         __builtin_amdgcn_sched_barrier(0);                                                              \
         _Pragma("unroll") for (int t = 0; t < 4; t++)                                                    \
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AC[t]), __builtin_bit_cast(bf16x8, BC), acc[t], 0, 0, 0); \
@@ -134,6 +134,9 @@ int main() {
     run("2 waves/SIMD, deep prefetch: + 4 from LDS + 1 from L1", kdeep<4, 2>, 2, d, f, out, blocks);
     run("2 waves/SIMD, deep prefetch: + 2 from LDS + 1 from L1", kdeep<2, 2>, 2, d, f, out, blocks);
     run("2 waves/SIMD, deep prefetch: + 1 from LDS + 1 from L1", kdeep<1, 2>, 2, d, f, out, blocks);
+    run("2 waves/SIMD, deep prefetch: + 4 from LDS + the filter fragment from LDS too", kdeep<4, 2, true>, 2, d, f, out, blocks);
+    run("2 waves/SIMD, deep prefetch: + 2 from LDS + the filter fragment from LDS too", kdeep<2, 2, true>, 2, d, f, out, blocks);
+    run("1 wave/SIMD, deep prefetch: + 4 from LDS + the filter fragment from LDS too", kdeep<4, 1, true>, 1, d, f, out, blocks);
     run("1 wave/SIMD: operands stay in registers (again)", k<0, 0, 1>, 1, d, f, out, blocks);
     return 0;
 }
