@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BIDATE_LIB') or os.path.join(_HERE, 'csrc', 'libbidate_hip.so')
 
-BDN_F32, BDN_BF16, BDN_BF16X3 = 0, 1, 2
+BDN_F32, BDN_BF16, BDN_BF16X3, BDN_BF16X2 = 0, 1, 2, 3
 IN_PLAIN, IN_BNRELU = 0, 1
 WG_SIMPLE, WG_ROLE = 1, 5
 

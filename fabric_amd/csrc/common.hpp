@@ -32,7 +32,7 @@ int bdn_pack_weights_x3(const float* w_oihw, void* wf, void* wd, int Cout, int C
 // bdn_pack_weights_multi's device record: one per layer
 struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, Cinp, pad_; };
 int bdn_pack_weights_x3_multi(const PackDesc* desc, int n_layers, hipStream_t st);
-int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, int taps, hipStream_t st);
+int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, int taps, int terms, hipStream_t st);
 
 // ---------------------------------------------------------------- division by a launch-invariant integer
 // n / d for 0 <= n < 2^31 as one v_mul_hi_u32 and a shift (the round-up multiplier; exhaustively checked against n / d on the host

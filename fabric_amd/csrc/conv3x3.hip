@@ -31,6 +31,7 @@ struct ConvArgs {
     const float* in_bn;          // [G][4][C0] or null
     int imgs_per_group;
     const void* w;               // fragment-ordered filter image (common.hpp: wfrag_index)
+    int w_kgroups;               // records per (cout block, tap) row of that image; 0 = (C0 + C1) / KCH.  BDN_BF16X2 walks the first two thirds of a bf16x3 row
     const float* bias;           // [Cout] or null
     void* out;                   // [N,H,W,Cout]
     float* stats_partial;        // [n_mtiles][2][Cout] or null
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     // the fragment-ordered image.  Named scalars on purpose (register arrays that meet a scheduling fence were
     // kept in scratch).  Record index: ((cout/32 * 9 + tap) * Cin/KCH + c/KCH); see wfrag_index in common.hpp.
     constexpr int KCH = 32 / CF::ES;                     // channels per k-group
-    const int kgroups = Cin / KCH;                       // records per (cout block, tap)
+    const int kgroups = a.w_kgroups ? a.w_kgroups : Cin / KCH;   // records per (cout block, tap)
     // wave-uniform base (scalar registers) + the lane's 16-byte slot as a 32-bit offset: the loads take the
     // SGPR-base addressing form and need no per-load 64-bit vector address arithmetic
     const int wn_u = __builtin_amdgcn_readfirstlane(wn);
@@ -628,15 +629,18 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     if (in_mode == BDN_IN_BNRELU && in1) BDN_FAIL(BDN_E_ARG, "conv3x3: two-source input must be plain");
     ConvArgs a;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ld0 = C0; a.ld1 = C1;
-    if (dtype == BDN_BF16X3) {
+    a.w_kgroups = 0;
+    if (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) {
         // in0 is the split operand of bdn_split_pack: [N,H,W,2*C0] bf16 = hi(C0) | lo(C0).  K = [hi | lo | hi] against the
         // packed filter image [w_hi | w_hi | w_lo]: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo accumulate in the same f32 MFMA tile.
+        // BDN_BF16X2: K = [hi | lo] against the first two thirds of every image row -- a_hi*w_hi + a_lo*w_hi
         if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3x3(bf16x3): one split-packed, plain operand (bdn_split_pack does cat / BatchNorm+ReLU)");
         if (C0 % 16) BDN_FAIL(BDN_E_SHAPE, "conv3x3(bf16x3): C0=%d must be a multiple of 16", C0);
-        a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0;
+        if (dtype == BDN_BF16X3) { a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0; }
+        else { a.in1 = nullptr; a.C0 = 2 * C0; a.C1 = 0; a.ld0 = 2 * C0; a.ld1 = 0; a.w_kgroups = 3 * C0 / 16; }
     }
     {   // the kernels address every tensor as one uniform base + a 32-bit byte offset
-        const size_t npix = (size_t)N * H * W, es = dtype == BDN_F32 ? 4 : 2, oes = dtype == BDN_BF16 ? 2 : 4;
+        const size_t npix = (size_t)N * H * W, es = dtype == BDN_F32 ? 4 : 2, oes = dtype == BDN_BF16 ? 2 : 4;      // (bf16x3 / bf16x2: bf16 operands, float32 outputs)
         const size_t widest = (size_t)(a.ld0 > a.ld1 ? a.ld0 : a.ld1);
         if (npix * widest * es >= ((size_t)1 << 32) || npix * (size_t)Cout * oes >= ((size_t)1 << 32))
             BDN_FAIL(BDN_E_SHAPE, "conv3x3: a tensor of N*H*W=%zu pixels reaches 4 GB; split the batch", npix);
@@ -663,8 +667,8 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
         if (C0 % 32 == 0 && C1 % 32 == 0) return dispatch_conv<float, 128>(a, g, st);
         if (C0 % 16 == 0 && C1 % 16 == 0) return dispatch_conv<float, 64>(a, g, st);
         BDN_FAIL(BDN_E_SHAPE, "conv3x3(f32): C0=%d C1=%d must be multiples of 16", C0, C1);
-    } else if (dtype == BDN_BF16X3) {
-        if (a.C1 % 64 == 0) return dispatch_conv_x3<128>(a, g, st);
+    } else if (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) {
+        if ((a.C0 / 2) % 64 == 0) return dispatch_conv_x3<128>(a, g, st);
         return dispatch_conv_x3<32>(a, g, st);
     }
     BDN_FAIL(BDN_E_ARG, "conv3x3: bad dtype %d", dtype);
@@ -760,7 +764,7 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
         BDN_FAIL(BDN_E_SHAPE, "conv3d: a tensor reaches 4 GB (32-bit byte offsets inside the kernel); split the batch");
     ConvArgs a;
     a.in1 = in; a.in0 = static_cast<const unsigned char*>(in) - slice; a.in2 = static_cast<const unsigned char*>(in) + slice;
-    a.C0 = C; a.C1 = C; a.ld0 = C; a.ld1 = C; a.Dz = D;
+    a.C0 = C; a.C1 = C; a.ld0 = C; a.ld1 = C; a.Dz = D; a.w_kgroups = 0;
     a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
     a.imgs_per_group = imgs_per_group * D;
     a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial; a.bs_z = nullptr; a.bs_bn = nullptr;

@@ -759,6 +759,7 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 //   flags bits 16-28 target grid size of the GEMM (0 = default, one block per CU)
 constexpr int WG_SIMPLE_MULT = 2;
 constexpr int WG_X3_SKIP = 1 << 30;          // internal plan flag, see wgrad_plan
+constexpr int WG_X3_TWO = 1 << 29;           // internal plan flag (BDN_BF16X2): only the hi half of dz -- the [lo, hi] quadrant is left out as well
 struct WgPlan { TileGeom g; int S, per_split, n_cot, n_cit; bool ksplit; int variant; int x3h, n_tiles; };
 static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group, int in_mode, int flags) {
     WgPlan p;
@@ -769,7 +770,7 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
     p.ksplit = Cin <= 32;
     // internal flag (bit 30, set by the bf16x3 entry on its doubled-operand call): leave the lo x lo quadrant out
     p.x3h = ((flags >> 30) & 1) && p.n_cot % 2 == 0 && p.n_cit % 2 == 0 ? p.n_cot / 2 : 0;
-    const int tiles = p.n_cot * p.n_cit - (p.x3h ? p.x3h * (p.n_cit / 2) : 0);
+    const int tiles = (p.x3h && ((flags >> 29) & 1)) ? p.x3h * p.n_cit : p.n_cot * p.n_cit - (p.x3h ? p.x3h * (p.n_cit / 2) : 0);
     p.n_tiles = tiles;
     // the pipelined kernels cover full 64-channel input tiles on 8x16 spatial tiles whose tensors stay below 2^31 elements
     const size_t cmax = (size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1));
@@ -795,8 +796,9 @@ static WgPlan wgrad_plan(int dtype, int N, int H, int W, int Cout, int C0, int C
 extern "C" size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, int Cout, int C0, int C1, int imgs_per_group,
                                                int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0 || imgs_per_group <= 0) return 0;
-    if (dtype == BDN_BF16X3)      // doubled operands ([hi | lo] x [hi | lo]) through the bf16 plan + the [2 Cout][2 Cin][9] tile the quadrants are summed from
-        return bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN, flags | WG_X3_SKIP)
+    if (dtype == BDN_BF16X3 || dtype == BDN_BF16X2)      // doubled operands ([hi | lo] x [hi | lo]) through the bf16 plan + the [2 Cout][2 Cin][9] tile the quadrants are summed from
+        return bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN,
+                                            flags | WG_X3_SKIP | (dtype == BDN_BF16X2 ? WG_X3_TWO : 0))
                + (size_t)4 * Cout * (C0 + C1) * 9 * sizeof(float);
     const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags);
     return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * (C0 + C1) * sizeof(float);
@@ -834,18 +836,19 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
                                     int N, int H, int W, int phases, void* stream) {
     if (!dz || !in0 || !partial || !dw_oihw) BDN_FAIL(BDN_E_ARG, "wgrad: null pointer");
     if (!(phases & 3)) BDN_FAIL(BDN_E_ARG, "wgrad: phases must select the GEMM (1), the reduction (2) or both (3)");
-    if (dtype == BDN_BF16X3) {
+    if (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) {
+        const int xfl = WG_X3_SKIP | (dtype == BDN_BF16X2 ? WG_X3_TWO : 0);          // BDN_BF16X2: dw = T[hi,hi] + T[hi,lo] (dz rounded to bf16)
         // dz = split operand [N,H,W,2 Cout] (hi | lo), in0 = split operand [N,H,W,2 C0] from bdn_split_pack (which did any cat /
         // BatchNorm+ReLU): the bf16 GEMM on the doubled operands yields T = [2 Cout][2 C0][9]; dw = T[hi,hi] + T[hi,lo] + T[lo,hi].
         if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "wgrad(bf16x3): one split-packed, plain operand");
         if (Cout <= 0 || Cout % 32 || C0 <= 0 || C0 % 8 || Cin_real <= 0 || Cin_real > C0)
             BDN_FAIL(BDN_E_SHAPE, "wgrad(bf16x3): Cout=%d must be a multiple of 32, C0=%d of 8, Cin_real=%d <= C0", Cout, C0, Cin_real);
-        const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * C0, 0, imgs_per_group, BDN_IN_PLAIN, phases | WG_X3_SKIP);
+        const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * C0, 0, imgs_per_group, BDN_IN_PLAIN, phases | xfl);
         float* tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(partial) + gemm_bytes);
         const int rc = bdn_conv3x3_wgrad_ex(BDN_BF16, dz, 2 * Cout, in0, 2 * C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group,
-                                            partial, tile, 2 * C0, N, H, W, phases | WG_X3_SKIP, stream);
+                                            partial, tile, 2 * C0, N, H, W, phases | xfl, stream);
         if (rc) return rc;
-        if (phases & 2) return bdn_wgrad_x3_combine(tile, dw_oihw, Cout, C0, Cin_real, 9, reinterpret_cast<hipStream_t>(stream));
+        if (phases & 2) return bdn_wgrad_x3_combine(tile, dw_oihw, Cout, C0, Cin_real, 9, dtype == BDN_BF16X2 ? 2 : 3, reinterpret_cast<hipStream_t>(stream));
         return BDN_OK;
     }
     if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
@@ -949,7 +952,7 @@ extern "C" int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void*
         float* tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(partial) + gemm_bytes);
         const int rc = bdn_conv3d_wgrad(BDN_BF16, dz, 2 * Cout, in, 2 * C, partial, tile, 2 * C, N, D, H, W, stream);
         if (rc) return rc;
-        return bdn_wgrad_x3_combine(tile, dw_oidhw, Cout, C, Cin_real, 27, reinterpret_cast<hipStream_t>(stream));
+        return bdn_wgrad_x3_combine(tile, dw_oidhw, Cout, C, Cin_real, 27, 3, reinterpret_cast<hipStream_t>(stream));
     }
     if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3d_wgrad: bad dtype %d (bf16 / f32 / bf16x3)", dtype);
     const int NS = N * D;

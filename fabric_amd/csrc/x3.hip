@@ -133,19 +133,20 @@ int bdn_pack_weights_x3(const float* w_oihw, void* wf, void* wd, int Cout, int C
 // dw[co][ci][t] = T[co][ci][t] + T[co][Cinp + ci][t] + T[Cout + co][ci][t],  T = f32 [2 Cout][2 Cinp][9] (the doubled-operand
 // weight gradient: hi*hi + hi*lo + lo*hi; the lo*lo quadrant is dropped)
 // (taps = 9, or 27 for the 3x3x3 convolution)
-__global__ void wgrad_x3_combine_kernel(const float* __restrict__ T, float* __restrict__ dw, int Cout, int Cinp, int Cin_real, int taps) {
+__global__ void wgrad_x3_combine_kernel(const float* __restrict__ T, float* __restrict__ dw, int Cout, int Cinp, int Cin_real, int taps, int terms) {
     const size_t total = (size_t)Cout * Cin_real * taps;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = i % taps; const size_t r = i / taps; const int ci = r % Cin_real; const int co = r / Cin_real;
     const size_t ld = (size_t)2 * Cinp * taps;
-    dw[i] = T[(size_t)co * ld + (size_t)ci * taps + t] + T[(size_t)co * ld + (size_t)(Cinp + ci) * taps + t]
-          + T[(size_t)(Cout + co) * ld + (size_t)ci * taps + t];
+    float v = T[(size_t)co * ld + (size_t)ci * taps + t] + T[(size_t)co * ld + (size_t)(Cinp + ci) * taps + t];
+    if (terms == 3) v += T[(size_t)(Cout + co) * ld + (size_t)ci * taps + t];      // (BDN_BF16X2 never computed the lo rows)
+    dw[i] = v;
 }
 
-int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, int taps, hipStream_t st) {
+int bdn_wgrad_x3_combine(const float* T, float* dw, int Cout, int Cinp, int Cin_real, int taps, int terms, hipStream_t st) {
     const size_t total = (size_t)Cout * Cin_real * taps;
-    hipLaunchKernelGGL(wgrad_x3_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, T, dw, Cout, Cinp, Cin_real, taps);
+    hipLaunchKernelGGL(wgrad_x3_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, T, dw, Cout, Cinp, Cin_real, taps, terms);
     BDN_CHECK_LAUNCH("wgrad_x3_combine");
     return BDN_OK;
 }

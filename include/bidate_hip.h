@@ -30,7 +30,12 @@
 extern "C" {
 #endif
 
-enum { BDN_F32 = 0, BDN_BF16 = 1, BDN_BF16X3 = 2 };   /* BDN_BF16X3: float32 tensors, GEMM operands split into bf16 hi + lo (3 MFMAs per product) */
+enum { BDN_F32 = 0, BDN_BF16 = 1, BDN_BF16X3 = 2,     /* BDN_BF16X3: float32 tensors, GEMM operands split into bf16 hi + lo (3 MFMAs per product) */
+       BDN_BF16X2 = 3 };  /* the BACKWARD GEMMs of the bf16x3 setting with two of the three terms, on the same operands and filter images as
+                           * BDN_BF16X3 -- bdn_conv3x3 / bdn_conv3x3_dgrad_bs (data gradient): K = [dz_hi | dz_lo] against [w_hi | w_hi], i.e. the
+                           * filter rounded to bf16, dz in full; bdn_conv3x3_wgrad_ex / bdn_wgrad_workspace_bytes_ex: dz_hi x [a_hi | a_lo], i.e.
+                           * dz rounded, the activations in full (autograd of models/unet_parts.py:13,16 to ~1e-3 relative instead of ~2e-5).
+                           * Accepted by those entry points only. */
 enum { BDN_OK = 0, BDN_E_ARG = -1, BDN_E_SHAPE = -2, BDN_E_HIP = -3 };
 enum { BDN_IN_PLAIN = 0, BDN_IN_BNRELU = 1 };
 

@@ -981,6 +981,45 @@ def test_conv3x3_bf16x3_forward_dgrad_wgrad(case):
     assert_close('x3 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz, padding=1), 1e-4)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 1), (2, 8, 8, 128, 64, 2), (3, 19, 33, 64, 128, 3), (2, 12, 12, 192, 64, 2)])
+def test_conv3x3_bf16x2_backward_gemms(case):
+    """BDN_BF16X2, the two-term backward of the bf16x3 setting, on the operands and filter images of BDN_BF16X3: the data gradient equals
+    the exact data gradient with the FILTER rounded to bf16 (dz in full), the weight gradient the exact one with DZ rounded to bf16 (the
+    activations in full) -- each within 1e-4 of the tensor's magnitude (autograd of models/unet_parts.py:13,16)."""
+    N, H, W, Cin, Cout, ipg = case
+    lib = _lib.load()
+    X3, X2 = _lib.BDN_BF16X3, _lib.BDN_BF16X2
+    x = _rand((N, Cin, H, W), 321)
+    w = _rand((Cout, Cin, 3, 3), 322) * 0.1
+    dz = _rand((N, Cout, H, W), 323)
+    sp = torch.empty(N, H, W, 2 * Cin, dtype=torch.bfloat16, device='cuda')
+    xd = to_nhwc('fp32', x)
+    _lib.call('bdn_split_pack', xd.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg, sp.data_ptr(), N, H, W, st())
+    wf = torch.empty(Cout, 9, 3 * Cin, dtype=torch.bfloat16, device='cuda')
+    wd = torch.empty(Cin, 9, 3 * Cout, dtype=torch.bfloat16, device='cuda')
+    wdev = dev(w)
+    _lib.call('bdn_pack_weights', X3, wdev.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin, Cin, st())
+    dzd = to_nhwc('fp32', dz)
+    spd = torch.empty(N, H, W, 2 * Cout, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', dzd.data_ptr(), Cout, None, 0, IN_PLAIN, None, ipg, spd.data_ptr(), N, H, W, st())
+    dA = torch.full((N, H, W, Cin), float('nan'), device='cuda')
+    _lib.call('bdn_conv3x3', X2, spd.data_ptr(), Cout, None, 0, IN_PLAIN, None, ipg, wd.data_ptr(), None, dA.data_ptr(), None,
+              N, H, W, Cin, st())
+    torch.cuda.synchronize()
+    w_hi, dz_hi = w.to(torch.bfloat16).float(), dz.to(torch.bfloat16).float()
+    assert_close('x2 dgrad', from_nhwc(dA), torch.nn.grad.conv2d_input(x.shape, w_hi, dz, padding=1), 1e-4)
+    # ... and it is NOT the three-term product: the full-precision filter is further away than the rounded one
+    full = torch.nn.grad.conv2d_input(x.shape, w, dz, padding=1)
+    assert (from_nhwc(dA) - full).abs().max() > 3e-4 * full.abs().max()
+    nb = lib.bdn_wgrad_workspace_bytes_ex(X2, N, H, W, Cout, Cin, 0, ipg, IN_PLAIN, 3)
+    part = torch.empty(nb // 4, device='cuda')
+    dw = torch.full((Cout, Cin, 3, 3), float('nan'), device='cuda')
+    _lib.call('bdn_conv3x3_wgrad', X2, spd.data_ptr(), Cout, sp.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg,
+              part.data_ptr(), dw.data_ptr(), Cin, N, H, W, st())
+    torch.cuda.synchronize()
+    assert_close('x2 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz_hi, padding=1), 1e-4)
+
+
 def test_split_outputs_of_the_bf16x3_producers_equal_split_pack():
     """bf16x3 setting: bdn_product_pool_split / bdn_upsample2x_split / bdn_bn_bwd_apply_split store their float32 results directly as
     the [hi | lo] bf16 operands of the consuming GEMMs; each must equal bdn_split_pack of the float32 kernel's output bit for bit."""

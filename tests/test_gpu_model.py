@@ -123,6 +123,30 @@ def test_train_step_matches_reference(golden_dir, name, prec):
     assert d2.max() <= (0.25 if prec == 'bf16' else 1e-3)
 
 
+@pytest.mark.parametrize('name', CASES)
+def test_bf16x3_backward_two_and_three_terms(golden_dir, name):
+    """The bf16x3 setting's backward GEMMs keep two of the three split-product terms by default (engine.x3_bwd_terms = 2, BDN_BF16X2: the
+    filter rounded to bf16 in the data gradient, dz in the weight gradient; the forward -- the logits of north_star's 1e-3 bar -- always keeps
+    three).  Both backward forms meet the golden gradient bounds of test_train_step_matches_reference (autograd of models/unet_parts.py:13,16),
+    and they differ from each other by <= 1e-2 relative L2 over the whole gradient (measured 2-5e-3), 1 - cosine <= 1e-4."""
+    g, c, x1, x2, lbl = _load(golden_dir, name)
+    grads = {}
+    for terms in (3, 2):
+        model = filler.fill_module(BiDateNet(c, 2, precision='bf16x3')).cuda().train()
+        assert model.engine().x3_bwd_terms == 2                    # the default
+        model.engine().x3_bwd_terms = terms
+        logits = model(x1, x2)
+        _tversky_torch(logits, lbl).backward()
+        assert (logits.detach().cpu() - torch.from_numpy(g['logits'])).abs().max() <= 1e-3
+        gerr, gkey, gcos = _grad_errors(model, g)
+        assert gerr < 6e-2 and gcos > 0.9999, (terms, gkey, gerr, gcos)
+        grads[terms] = torch.cat([p.grad.flatten() for p in model.parameters()]).double()
+    rel = ((grads[2] - grads[3]).norm() / grads[3].norm()).item()
+    cos = torch.nn.functional.cosine_similarity(grads[2], grads[3], dim=0).item()
+    print(f'\n[{name}] two- vs three-term backward: relative L2 {rel:.2e}, 1 - cosine {1 - cos:.1e}')
+    assert rel <= 1e-2 and 1 - cos <= 1e-4
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_two_forwards_before_backward_keep_their_own_activations(golden_dir, prec):
     """Plain autograd usage the reference supports: two micro-batches (and an eval forward in between) before one backward.
