@@ -552,37 +552,58 @@ def val_f1_leg(dev, steps=60, B=8, S=128, lr=0.02):
     return out
 
 
-def conv3d_leg(dev, N=2, D=5, S=128, cin=13, cout=64, iters=5):
+def conv3d_leg(dev, samples=(2, 16), D=5, S=128, cin=13, cout=64, iters=5):
     """BASELINE.json configs[3] (multi-date stack, 5 dates x 13 bands x 128 x 128) as far as a reference exists for it -- it does not
-    (UNetLSTM/ is an empty sub-module), so PARITY IS UNPINNED: the 3x3x3 `DoubleConv3d` block (tests/test_gpu_conv3d.py checks it against
-    torch.nn.Conv3d / BatchNorm3d) forward + backward at N x 5 x 13 x 128 x 128, and the same for the 64 -> 64 block that follows it."""
-    from fabric_amd.conv3d import DoubleConv3d
-    out = {'workload': f'DoubleConv3d forward + backward, {N} samples of {D} dates x {cin} bands x {S} x {S}, bf16 (BASELINE configs[3] shapes)',
-           'parity': 'unpinned: the reference holds no 3-D model source; block checked against torch.nn in tests/test_gpu_conv3d.py'}
-    for ci, co in ((cin, cout), (cout, cout)):
-        blk = DoubleConv3d(ci, co, precision='bf16')
-        g = torch.Generator(device='cpu').manual_seed(ci)
-        blk.load({'conv.0.weight': 0.05 * torch.randn(co, ci, 3, 3, 3, generator=g), 'conv.3.weight': 0.05 * torch.randn(co, co, 3, 3, 3, generator=g)})
-        cp = (ci + 15) // 16 * 16
-        x = torch.zeros(N, D, S, S, cp, dtype=torch.bfloat16, device=dev)
-        x[..., :ci] = torch.randn(N, D, S, S, ci, generator=g).to(dev).to(torch.bfloat16)
-        dy = torch.randn(N, D, S, S, co, generator=g).to(dev).to(torch.bfloat16)
+    (UNetLSTM/ is an empty sub-module), so PARITY IS UNPINNED: the 3x3x3 convolution of the two full-resolution layers a 3-D U-Net with
+    BiDateNet's widths starts with (13 -> 64 and 64 -> 64; tests/test_gpu_conv3d.py checks them against torch.nn.functional.conv3d /
+    torch.nn.grad) -- forward, data gradient and weight gradient timed SEPARATELY, at the config's own 2 samples (10 slices = 640 blocks:
+    1.25 rounds of the chip) and at 16 samples (80 slices: a chip-filling batch), plus the whole DoubleConv3d block forward + backward."""
+    from fabric_amd.conv3d import Conv3d3x3, DoubleConv3d
 
-        def fb():
-            blk.forward(x)
-            blk.backward(dy)
-        fb(); torch.cuda.synchronize()
+    def timeit(fn):
+        fn(); fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            fb()
+            fn()
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        vox = N * D * S * S
-        # conv.0: fwd + wgrad (+ dgrad when the padded input is >= 64 channels); conv.3: fwd + dgrad + wgrad
-        fl = 2.0 * vox * 27 * (co * ci * (3 if cp % 64 == 0 else 2) + co * co * 3)
-        out[f'{ci}->{co}'] = {'ms_fwd_bwd': ms, 'GFLOP': fl / 1e9, 'TFLOPs': fl / ms / 1e9, 'frac_of_mfma_peak': fl / ms / 1e9 / (MFMA_BF16_PEAK / 1e12),
-                              'samples_per_s': N / ms * 1e3}
+        return e0.elapsed_time(e1) / iters
+
+    out = {'workload': f'3x3x3 convolution {cin}->{cout} and {cout}->{cout} on {D} dates x {S} x {S}, bf16 (BASELINE configs[3] shapes), per direction',
+           'parity': 'unpinned: the reference holds no 3-D model source; operator and block checked against torch.nn in tests/test_gpu_conv3d.py'}
+    peak = MFMA_BF16_PEAK / 1e12
+    for N in samples:
+        for ci, co in ((cin, cout), (cout, cout)):
+            g = torch.Generator(device='cpu').manual_seed(ci)
+            w = (0.05 * torch.randn(co, ci, 3, 3, 3, generator=g)).to(dev)
+            op = Conv3d3x3(w, torch.zeros(co, device=dev))
+            cp = op.cp
+            x = torch.zeros(N, D, S, S, cp, dtype=torch.bfloat16, device=dev)
+            x[..., :ci] = torch.randn(N, D, S, S, ci, generator=g).to(dev).to(torch.bfloat16)
+            dy = torch.randn(N, D, S, S, co, generator=g).to(dev).to(torch.bfloat16)
+            fl = 2.0 * N * D * S * S * 27 * co * ci          # algorithmic FLOP of one direction (real input channels)
+            rec = {'GFLOP_per_direction': fl / 1e9, 'slices': N * D}
+            for what, fn in (('fwd', lambda: op.forward(x)), ('dgrad', (lambda: op.dgrad(dy)) if op.wd is not None else None),
+                             ('wgrad', lambda: op.wgrad(dy, x))):
+                if fn is None:
+                    rec[what] = None                              # a 13-band first layer has no data gradient
+                    continue
+                ms = timeit(fn)
+                rec[what] = {'ms': ms, 'TFLOPs': fl / ms / 1e9, 'frac_of_mfma_peak': fl / ms / 1e9 / peak}
+            blk = DoubleConv3d(ci, co, precision='bf16')
+            blk.load({'conv.0.weight': w.cpu(), 'conv.3.weight': 0.05 * torch.randn(co, co, 3, 3, 3, generator=g)})
+
+            def fb():
+                blk.forward(x)
+                blk.backward(dy)
+            ms = timeit(fb)
+            vox = N * D * S * S
+            flb = 2.0 * vox * 27 * (co * ci * (3 if cp % 64 == 0 else 2) + co * co * 3)
+            rec['double_conv_fwd_bwd'] = {'ms': ms, 'GFLOP': flb / 1e9, 'TFLOPs': flb / ms / 1e9, 'frac_of_mfma_peak': flb / ms / 1e9 / peak,
+                                          'samples_per_s': N / ms * 1e3}
+            out.setdefault(f'{N}x{D}', {})[f'{ci}->{co}'] = rec
+            del op, blk, x, dy
+            torch.cuda.empty_cache()
     return out
 
 

@@ -45,6 +45,9 @@ SIGNATURES = {
     'bdn_bn_finalize_workspace_bytes': (_sz, [_i, _i, _i]),
     'bdn_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_bn_eval': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
+    'bdn_bn_eval_fold_multi': (_i, [_vp, _i, _i, _f, _vp]),
+    'bdn_conv3x3_eval': (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_conv3x3_eval_cls': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'bdn_bn_bwd': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bdn_conv3d_num_mtiles': (_i, [_i, _i, _i, _i]),
@@ -72,6 +75,7 @@ SIGNATURES = {
     'bdn_overlap_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    'bdn_conv3x3_dgrad_bb_variant': (C.c_char_p, [_i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_dgrad_bb': (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),

@@ -215,6 +215,32 @@ extern "C" int bdn_bn_eval(const float* gamma, const float* beta, const float* r
     return BDN_OK;
 }
 
+// Eval-mode BatchNorm folded with the bias of the convolution in front of it, for every layer of a network in ONE launch (round 6):
+//   scale = gamma / sqrt(running_var + eps),  shift = beta - running_mean * scale     (exactly bn_eval_kernel's values)
+//   out[0][c] = scale,  out[1][c] = conv_bias[c] * scale + shift                      (one FMA)
+// so that the convolution's epilogue forms relu(acc * out[0] + out[1]) = relu(bn(acc + bias)).  nn.BatchNorm2d.eval() + nn.ReLU,
+// models/unet_parts.py:14-15,17-18 on the conv of :13,16.
+struct EvalFoldDesc { const float* gamma; const float* beta; const float* rm; const float* rv; const float* bias; float* out; int C, pad_; };
+__global__ void bn_eval_fold_kernel(const EvalFoldDesc* __restrict__ desc, float eps) {
+    const EvalFoldDesc d = desc[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    const float inv = 1.0f / sqrtf(d.rv[c] + eps);
+    const float scale = d.gamma[c] * inv;
+    const float shift = d.beta[c] - d.rm[c] * scale;
+    d.out[c] = scale;
+    d.out[d.C + c] = d.bias ? fmaf(d.bias[c], scale, shift) : shift;
+}
+
+extern "C" int bdn_bn_eval_fold_multi(const void* desc, int n_layers, int max_C, float eps, void* stream) {
+    if (!desc) BDN_FAIL(BDN_E_ARG, "bn_eval_fold_multi: null pointer");
+    if (n_layers <= 0 || max_C <= 0) BDN_FAIL(BDN_E_SHAPE, "bn_eval_fold_multi: n_layers=%d max_C=%d", n_layers, max_C);
+    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3((max_C + 255) / 256, n_layers), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const EvalFoldDesc*>(desc), eps);
+    BDN_CHECK_LAUNCH("bn_eval_fold_multi");
+    return BDN_OK;
+}
+
 // ---------------------------------------------------------------- backward (BatchNorm2d + ReLU)
 // Thread t owns channel unit t % CU and pixel lane t / CU (CU = C / EPU divides 256); a block covers
 // pix_per_block pixels of ONE group.

@@ -162,6 +162,16 @@ __device__ __forceinline__ uint4 bnrelu_unit<bf16s>(const uint4& u, const float*
                       bnrelu_pair(u.z, sc[4], sc[5], sh[4], sh[5]), bnrelu_pair(u.w, sc[6], sc[7], sh[6], sh[7]));
 }
 
+template <int N> __device__ __forceinline__ float dpp_row_shl(float v) {     // lane i <- lane i + N of its row of 16 (0 beyond the row)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+template <int CU> __device__ __forceinline__ float first_lane_sum(float v) {
+    static_assert(CU == 8 || CU == 16, "lanes per pixel");
+    if constexpr (CU == 16) v += dpp_row_shl<8>(v);
+    v += dpp_row_shl<4>(v); v += dpp_row_shl<2>(v); v += dpp_row_shl<1>(v);
+    return v;
+}
+
 // Filter image in MFMA fragment order (what conv3x3_kernel streams from L2): one contiguous 1 KB record per
 // (32 output channels, tap, k-group of 32 bytes of input channels); inside a record lane l owns 16 bytes:
 // output channel 32*cb + (l & 31), input channels kgroup*KCH + (l >> 5)*EPU + [0, EPU).

@@ -48,6 +48,17 @@ struct ConvArgs {
     //   a = scale,  b = -scale invstd s1/M,  c = -scale s0/M - b mean      ( = scale (g - s0/M - xhat s1/M), bdn_bn_bwd_apply's value up to
     // rounding) -- two FMAs per element, no compare, three constants -- and the blocks of column tile 0 also store their tile's dz to bb_dz
     const void* bb_z; const float* bb_bn; const float* bb_sums; void* bb_dz; float bb_invM;
+    // eval-mode launches (template flag EV; round 6, bdn_conv3x3_eval / bdn_conv3x3_eval_cls): nothing depends on batch statistics, so the
+    // epilogue applies the FOLLOWING BatchNorm (running statistics, folded with the conv bias by bdn_bn_eval_fold_multi) and the ReLU once,
+    //   a = relu(acc * ep_scale[c] + ep_shift[c]),
+    // and stores the ACTIVATION: every consumer stages plain bytes, there are no statistics partials and no finalize launches.  Optional:
+    //   ep_mul   [N,H,W,Cout]      the other date's activation of the same layer: what is stored to `out` is a * mul (relu(x_d2 * x_d1),
+    //                              models/bidate_model.py:35-38; both factors are >= 0) and a itself is not stored at all;
+    //   ep_pool  [N,H/2,W/2,Cout]  nn.MaxPool2d(2) of a (models/unet_parts.py:40; floor mode), from the tile in LDS;
+    //   cls_*    the 1x1 classifier (models/unet_parts.py:88-89) on a tile that holds all Cout = 64 channels: logits [N,ncls,H,W] f32 and / or
+    //            the class index (first maximum wins, train.py:199) as a [N,H,W] map or stitched into a scene mask (utils/inference.py:187-236).
+    const float* ep_scale; const float* ep_shift; const void* ep_mul; void* ep_pool;
+    const float* cls_w; const float* cls_b; int cls_n; float* cls_logits; unsigned char* cls_mask; const int* cls_origins; int cls_H, cls_W;
 };
 
 template <typename T> struct Mma;
@@ -112,7 +123,7 @@ struct ConvCfg {
 // ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 // the multi-chunk 64-wide instantiation on 8 x 16 tiles needs 171 registers: at three blocks per CU (168) it spilled three of them;
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     const int p_fall = D3 ? (n0 * a.H + y0) * a.W + x0 : 0;
     constexpr bool BRANCHFREE = !ONE;
     static_assert(!BB || (sizeof(T) == 2 && sizeof(TO) == 2 && !D3 && TI == 1), "BatchNorm backward on load: bf16 2-D launches, one image per tile");
+    static_assert(!EV || (!BB && !D3 && sizeof(T) == sizeof(TO)), "eval-mode epilogue: plain 2-D launches");
     uint4 preg[NPU];
     uint4 pregz[BB ? NPU : 1];                           // BB: the z units of the same pixels
 #define LOAD_PATCH(c0_)                                                                                  \
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         const int bs_ = D3 ? (c0_) / a.C0 : 0;             /* depth source of this chunk */               \
         const int bc_ = D3 ? (c0_) - bs_ * a.C0 : (c0_);   /* channel inside its source */                \
         const bool dvs_ = !D3 || ((dmask >> bs_) & 1u);                                                 \
-        const bool bn_ = a.in_bn != nullptr && (D3 || (c0_) < a.C0);                                    \
+        const bool bn_ = !EV && a.in_bn != nullptr && (D3 || (c0_) < a.C0);   /* eval-mode launches stage plain activations */ \
         float sc_[EPU], sh_[EPU];                          /* all units of a thread share one channel group */ \
         if (bn_) {                                                                                      \
             const float* ps_ = bn_row(a.in_bn, grp, 2, a.C0) + bc_ + p_sub;                             \
@@ -376,6 +388,160 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
 #undef LOAD_PATCH
 #undef STORE_PATCH
 
+    // ------------------------------------------------------------------ eval-mode epilogue (EV launches; see ConvArgs)
+    if constexpr (EV) {
+        unsigned char* otile = smem;
+        constexpr int UPR = BN * CF::OES / 16, OEPU = 16 / CF::OES, NIT = CF::BM * UPR / 256;
+        static_assert(256 % UPR == 0 && UPR <= 64 && (CF::BM * UPR) % 256 == 0, "a thread keeps one channel unit through the copy-out loop");
+        constexpr bool PRE = NIT <= 8;
+        constexpr int NPRE = PRE ? NIT : 1;
+        const unsigned orow = (unsigned)a.Cout * CF::OES;
+        unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)col0 * CF::OES;
+        const unsigned char* mulp = reinterpret_cast<const unsigned char*>(a.ep_mul) + (size_t)col0 * CF::OES;
+        const bool has_mul = a.ep_mul != nullptr, has_out = a.out != nullptr;       // block-uniform
+#define OUT_OFS(i_, dst_)                                   /* byte offset of copy-out unit i_ in the output tensor, ~0 = outside the image */ \
+        {                                                                                               \
+            const int u_ = tid + (i_) * 256, slot_ = u_ / UPR, sub_ = u_ % UPR;                         \
+            int ti_, py_, px_; TL::slot_to_nyx(slot_, ti_, py_, px_);                                   \
+            const int n_ = n0 + ti_, y_ = y0 + py_, x_ = x0 + px_;                                      \
+            dst_ = (n_ < a.N && y_ < a.H && x_ < a.W) ? (unsigned)((n_ * a.H + y_) * a.W + x_) * orow + (unsigned)sub_ * 16u : 0xffffffffu; \
+        }
+        unsigned oofs[NPRE];
+        uint4 mq[NPRE];
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < NPRE; i++) OUT_OFS(i, oofs[i])
+            if (has_mul) {                                   // the other date's units: requested a whole accumulator pass ahead of their use
+#pragma unroll
+                for (int i = 0; i < NPRE; i++) mq[i] = *reinterpret_cast<const uint4*>(mulp + (oofs[i] != 0xffffffffu ? oofs[i] : 0u));
+            }
+        }
+        // accumulators -> activation -> LDS (rounded to the storage type: what every consumer of the tensor sees)
+#pragma unroll
+        for (int nj = 0; nj < NJ; nj++) {
+            const int col = (wn * NJ + nj) * 32 + l31;
+            unsigned char* ob_ = otile + (wm * MI * 32 + 4 * half) * CF::OSTR + col * CF::OES;
+            const float esc = a.ep_scale[col0 + col], esh = a.ep_shift[col0 + col];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int srel_ = mi * 32 + (r & 3) + 8 * (r >> 2);
+                    *reinterpret_cast<TO*>(ob_ + srel_ * CF::OSTR) = from_f<TO>(fmaxf(fmaf(acc[mi][nj][r], esc, esh), 0.f));
+                }
+            }
+        }
+        __syncthreads();
+        if (a.cls_w != nullptr) {
+            // 1x1 classifier on the tile (Cout == BN == 64: the UPR lanes of a pixel hold all its channels).  Same association as
+            // outc_fwd_kernel<T, 2, UPR>: eight (four) channels per lane in ascending order, then the DPP row sums -- the logits are
+            // bit-identical to bdn_outc_fwd on the stored activation.
+            if constexpr (BN == 64 && (UPR == 8 || UPR == 16)) {
+                const int bsub = (tid % UPR) * OEPU;
+                float wk[2][OEPU], bk[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int kk = k < a.cls_n ? k : 0;
+                    const float bv = a.cls_b[kk];
+                    bk[k] = k < a.cls_n ? bv : 0.f;
+#pragma unroll
+                    for (int i = 0; i < OEPU; i++) { const float wv = a.cls_w[kk * 64 + bsub + i]; wk[k][i] = k < a.cls_n ? wv : 0.f; }
+                }
+                const int hw = a.H * a.W;
+#pragma unroll 2
+                for (int i = 0; i < NIT; i++) {
+                    const int u_ = tid + i * 256, slot_ = u_ / UPR;
+                    int ti_, py_, px_; TL::slot_to_nyx(slot_, ti_, py_, px_);
+                    const int n_ = n0 + ti_, y_ = y0 + py_, x_ = x0 + px_;
+                    const bool in_ = n_ < a.N && y_ < a.H && x_ < a.W;
+                    const uint4 v = *reinterpret_cast<const uint4*>(otile + slot_ * CF::OSTR + (u_ % UPR) * 16);
+                    float f[OEPU], l0 = 0.f, l1 = 0.f;
+                    Unit<TO>::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < OEPU; e++) { l0 = fmaf(f[e], wk[0][e], l0); l1 = fmaf(f[e], wk[1][e], l1); }
+                    l0 = first_lane_sum<UPR == 16 ? 16 : 8>(l0); l1 = first_lane_sum<UPR == 16 ? 16 : 8>(l1);
+                    if (in_ && has_out) *reinterpret_cast<uint4*>(outp + ((unsigned)((n_ * a.H + y_) * a.W + x_) * orow + (unsigned)(u_ % UPR) * 16u)) = v;
+                    if (in_ && (tid % UPR) == 0) {
+                        l0 += bk[0]; l1 += bk[1];
+                        const int q_ = y_ * a.W + x_;
+                        if (a.cls_logits) {
+                            a.cls_logits[((size_t)n_ * a.cls_n) * hw + q_] = l0;
+                            if (a.cls_n > 1) a.cls_logits[((size_t)n_ * a.cls_n + 1) * hw + q_] = l1;
+                        }
+                        if (a.cls_mask) {
+                            const unsigned char arg = (a.cls_n > 1 && l1 > l0) ? 1 : 0;           // first maximum wins ties (train.py:199)
+                            if (!a.cls_origins) a.cls_mask[(size_t)n_ * hw + q_] = arg;
+                            else {
+                                // the stitching rule of argmax_stitch_kernel (scene.hip): a pixel of a far-edge band is written only by a tile anchored on it
+                                const int ty0 = a.cls_origins[2 * n_], tx0 = a.cls_origins[2 * n_ + 1];
+                                const int sy = ty0 + y_, sx = tx0 + x_;
+                                const bool tyb = ty0 == a.cls_H - a.H, txb = tx0 == a.cls_W - a.W;
+                                const bool pyb = sy >= a.cls_H - a.H, pxb = sx >= a.cls_W - a.W;
+                                if (tyb == pyb && txb == pxb) a.cls_mask[(size_t)sy * a.cls_W + sx] = arg;
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
+        // copy-out: 16-byte NHWC units; with ep_mul what leaves is the date product (both factors rounded activations, as fuse_product_kernel forms it)
+#define COPY_UNIT(i_, o_, mexpr_)                                                                        \
+        if ((o_) != 0xffffffffu) {                                                                      \
+            const int u_ = tid + (i_) * 256;                                                            \
+            uint4 v = *reinterpret_cast<const uint4*>(otile + (u_ / UPR) * CF::OSTR + (u_ % UPR) * 16); \
+            if (has_mul) {                                                                              \
+                float fa[OEPU], fb[OEPU];                                                               \
+                Unit<TO>::unpack(v, fa); Unit<TO>::unpack(mexpr_, fb);                                  \
+                _Pragma("unroll") for (int e = 0; e < OEPU; e++) fa[e] *= fb[e];                         \
+                v = Unit<TO>::pack(fa);                                                                 \
+            }                                                                                           \
+            *reinterpret_cast<uint4*>(outp + (o_)) = v;                                                 \
+        }
+        if (has_out) {
+            if constexpr (PRE) {
+#pragma unroll
+                for (int i = 0; i < NPRE; i++) COPY_UNIT(i, oofs[i], mq[i])
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < NIT; i++) {
+                    unsigned o; OUT_OFS(i, o)
+                    COPY_UNIT(i, o, *reinterpret_cast<const uint4*>(mulp + o))
+                }
+            }
+        }
+#undef COPY_UNIT
+#undef OUT_OFS
+        if (a.ep_pool != nullptr) {
+            // MaxPool2d(2) of the tile's own activation (still in LDS, untouched by the product above): tiles start on even rows / columns,
+            // so every 2x2 window lies inside one tile; floor mode drops the window of a trailing odd row / column
+            constexpr int PHT = TH / 2, PWT = TW / 2, NPP = TI * PHT * PWT * UPR;
+            const int Ho = a.H / 2, Wo = a.W / 2;
+            unsigned char* poolp = reinterpret_cast<unsigned char*>(a.ep_pool) + (size_t)col0 * CF::OES;
+#pragma unroll
+            for (int i = 0; i < (NPP + 255) / 256; i++) {
+                const int u_ = tid + i * 256, pp_ = u_ / UPR, sub_ = u_ % UPR;
+                const int ti_ = pp_ / (PHT * PWT), r_ = pp_ % (PHT * PWT), py_ = r_ / PWT, px_ = r_ % PWT;
+                const int n_ = n0 + ti_, yo_ = y0 / 2 + py_, xo_ = x0 / 2 + px_;
+                if (u_ < NPP && n_ < a.N && yo_ < Ho && xo_ < Wo) {
+                    const unsigned char* w00 = otile + ((ti_ * TH + 2 * py_) * TW + 2 * px_) * CF::OSTR + sub_ * 16;
+                    float m[OEPU], f[OEPU];
+                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00), m);
+                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00 + CF::OSTR), f);
+#pragma unroll
+                    for (int e = 0; e < OEPU; e++) m[e] = fmaxf(m[e], f[e]);
+                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00 + TW * CF::OSTR), f);
+#pragma unroll
+                    for (int e = 0; e < OEPU; e++) m[e] = fmaxf(m[e], f[e]);
+                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00 + (TW + 1) * CF::OSTR), f);
+#pragma unroll
+                    for (int e = 0; e < OEPU; e++) m[e] = fmaxf(m[e], f[e]);
+                    *reinterpret_cast<uint4*>(poolp + ((unsigned)((n_ * Ho + yo_) * Wo + xo_) * orow + (unsigned)sub_ * 16u)) = Unit<TO>::pack(m);
+                }
+            }
+        }
+        return;
+    }
     // ------------------------------------------------------------------ epilogue (LDS reused)
     unsigned char* otile = smem;
     float* red = reinterpret_cast<float*>(smem + CF::BM * CF::OSTR);
@@ -527,17 +693,17 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
 static thread_local bool g_conv_query = false;
 static thread_local char g_conv_variant[160];
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
     if (g_conv_query) {
         // the full template spelling, so that a profiler can match rocprofv3's kernel names exactly ("bf16" = unsigned short)
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s>",
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s,%s>",
                  sizeof(T) == 2 ? "bf16" : "float", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false",
-                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false");
+                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false", EV ? "true" : "false");
         return BDN_OK;
     }
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB>;
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB, EV>;
     BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
@@ -566,23 +732,23 @@ static ConvPlan conv_plan(int N, int H, int W, int Cout, int imgs_per_group) {
     return p;
 }
 
-template <typename T, int CKB>
+template <typename T, int CKB, bool EV = false>
 static int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
     const bool one = (a.C0 + a.C1) * (int)sizeof(T) == CKB;
     // 64-wide outputs on 16x16 tiles: the single-chunk kernels (three blocks per CU share one L1) take the 2x2 wave
     // layout, whose waves stream half the filter bytes each (e1b: +9..12 %); with several chunks the 4x1 layout wins
-    if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true>(a, g.n_mtiles, st);
-    if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1>(a, g.n_mtiles, st);
+    if (g.TH == 16 && one) return launch_conv<T, CKB, 16, 16, 1, 64, 2, 2, true, T, false, false, EV>(a, g.n_mtiles, st);
+    if (g.TH == 16) return launch_conv<T, CKB, 16, 16, 1, 64, 4, 1, false, T, false, false, EV>(a, g.n_mtiles, st);
     if (g.TI == 1) {
         // 128-wide column tiles: 1x4 waves (each 128 pixels x 32 channels) stream half the filter bytes of the 2x2 layout
         // through the L1 and need half the ring registers; the A fragments are read from LDS by all four (+1.5 % overall)
-        if (p.BN == 128 && one) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, true>(a, g.n_mtiles, st);
-        if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4>(a, g.n_mtiles, st);
-        return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2>(a, g.n_mtiles, st);
+        if (p.BN == 128 && one) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, true, T, false, false, EV>(a, g.n_mtiles, st);
+        if (p.BN == 128) return launch_conv<T, CKB, 8, 16, 1, 128, 1, 4, false, T, false, false, EV>(a, g.n_mtiles, st);
+        return launch_conv<T, CKB, 8, 16, 1, 64, 2, 2, false, T, false, false, EV>(a, g.n_mtiles, st);
     }
-    if (p.BN == 128) return launch_conv<T, CKB, 8, 8, 2, 128, 2, 2>(a, g.n_mtiles, st);
-    return launch_conv<T, CKB, 8, 8, 2, 64, 2, 2>(a, g.n_mtiles, st);
+    if (p.BN == 128) return launch_conv<T, CKB, 8, 8, 2, 128, 2, 2, false, T, false, false, EV>(a, g.n_mtiles, st);
+    return launch_conv<T, CKB, 8, 8, 2, 64, 2, 2, false, T, false, false, EV>(a, g.n_mtiles, st);
 }
 
 // BatchNorm backward on load (bdn_conv3x3_dgrad_bb): the single-chunk shapes only (dz of a 64-channel layer) -- there the staging runs once,
@@ -650,6 +816,8 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.bs_z = bs_z; a.bs_bn = bs_bn; a.in2 = nullptr; a.Dz = 0;
     a.bb_z = bb_z; a.bb_bn = bb_bn; a.bb_sums = bb_sums; a.bb_dz = bb_dz; a.bb_invM = 1.f / (float)((size_t)imgs_per_group * H * W);
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
     const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -715,6 +883,74 @@ extern "C" int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const voi
                         z_prev, bn_prev, N, H, W, Cout, stream, z, bn, sums, dz_out);
 }
 
+extern "C" const char* bdn_conv3x3_dgrad_bb_variant(int N, int H, int W, int Cout, int imgs_per_group) {
+    g_conv_variant[0] = 0;
+    g_conv_query = true;
+    void* dummy = reinterpret_cast<void*>(16);             // never dereferenced: nothing is launched in query mode
+    const int rc = conv3x3_impl(BDN_BF16, dummy, 64, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group, dummy, nullptr, dummy, nullptr, nullptr, nullptr,
+                                N, H, W, Cout, nullptr, dummy, reinterpret_cast<const float*>(dummy), reinterpret_cast<const float*>(dummy), nullptr);
+    g_conv_query = false;
+    return rc == BDN_OK ? g_conv_variant : "";
+}
+
+// Eval-mode convolution stage (models/unet_parts.py:13-18 with the BatchNorm in eval mode): conv3x3 -> BatchNorm (running statistics, folded
+// with the conv bias into ep_scale / ep_shift by bdn_bn_eval_fold_multi) -> ReLU in ONE launch that stores the activation.  Optional fused
+// consumers: the date product (mul), MaxPool2d(2) (pool), the 1x1 classifier + argmax (+ scene stitching).  See ConvArgs.
+static int conv3x3_eval_impl(int dtype, const void* in0, int C0, const void* in1, int C1, const void* w, const float* ep_scale, const float* ep_shift,
+                             void* out, const void* mul, void* pool, const float* cls_w, const float* cls_b, int ncls, float* logits,
+                             unsigned char* mask, const int* origins, int Hs, int Ws, int N, int H, int W, int Cout, void* stream) {
+    if (!in0 || !w || !ep_scale || !ep_shift) BDN_FAIL(BDN_E_ARG, "conv3x3_eval: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval: bad N=%d H=%d W=%d", N, H, W);
+    if (Cout <= 0 || Cout % 64) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval: Cout=%d must be a multiple of 64", Cout);
+    if (in1 == nullptr) C1 = 0;
+    if (C1 < 0 || (in1 && C1 == 0)) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval: bad C1=%d", C1);
+    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3x3_eval: bad dtype %d (bf16 / f32)", dtype);
+    if (pool && (H < 2 || W < 2)) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval: pooling needs H, W >= 2");
+    if (cls_w) {
+        if (!cls_b || (!logits && !mask)) BDN_FAIL(BDN_E_ARG, "conv3x3_eval_cls: null pointer");
+        if (Cout != 64 || ncls < 1 || ncls > 2) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_cls: Cout=%d must be 64 and ncls=%d 1 or 2 (bdn_outc_fwd covers the rest)", Cout, ncls);
+        if (mul || pool) BDN_FAIL(BDN_E_ARG, "conv3x3_eval_cls: no product / pooling on the classifier stage");
+        if (origins && (!mask || Hs < H || Ws < W)) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_cls: stitching needs a mask of at least one tile");
+    } else if (!out) BDN_FAIL(BDN_E_ARG, "conv3x3_eval: null pointer");
+    const size_t es = dtype == BDN_F32 ? 4 : 2, npix = (size_t)N * H * W, widest = (size_t)(C0 > C1 ? C0 : C1);
+    if (npix * widest * es >= ((size_t)1 << 32) || npix * (size_t)Cout * es >= ((size_t)1 << 32))
+        BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval: a tensor of N*H*W=%zu pixels reaches 4 GB; split the batch", npix);
+    ConvArgs a;
+    a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ld0 = C0; a.ld1 = C1; a.in2 = nullptr; a.Dz = 0;
+    a.in_bn = nullptr; a.imgs_per_group = N; a.w = w; a.w_kgroups = 0; a.bias = nullptr; a.out = out; a.stats_partial = nullptr;
+    a.bs_z = nullptr; a.bs_bn = nullptr; a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mul = mul; a.ep_pool = pool;
+    a.cls_w = cls_w; a.cls_b = cls_b; a.cls_n = ncls; a.cls_logits = logits; a.cls_mask = mask; a.cls_origins = origins; a.cls_H = Hs; a.cls_W = Ws;
+    // no statistic groups in eval mode: two images of a small map may always share a tile
+    const ConvPlan g = conv_plan(N, H, W, Cout, N % 2 == 0 ? 2 : 1);
+    a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == BDN_BF16) {
+        if (C0 % 64 == 0 && C1 % 64 == 0) return dispatch_conv<bf16s, 128, true>(a, g, st);
+        if (C0 % 16 == 0 && C1 % 16 == 0) return dispatch_conv<bf16s, 32, true>(a, g, st);
+        BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval(bf16): C0=%d C1=%d must be multiples of 16", C0, C1);
+    }
+    if (C0 % 32 == 0 && C1 % 32 == 0) return dispatch_conv<float, 128, true>(a, g, st);
+    if (C0 % 16 == 0 && C1 % 16 == 0) return dispatch_conv<float, 64, true>(a, g, st);
+    BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval(f32): C0=%d C1=%d must be multiples of 16", C0, C1);
+}
+
+extern "C" int bdn_conv3x3_eval(int dtype, const void* in0, int C0, const void* in1, int C1, const void* w,
+                                const float* ep_scale, const float* ep_shift, void* out, const void* mul, void* pool,
+                                int N, int H, int W, int Cout, void* stream) {
+    return conv3x3_eval_impl(dtype, in0, C0, in1, C1, w, ep_scale, ep_shift, out, mul, pool, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0,
+                             N, H, W, Cout, stream);
+}
+
+extern "C" int bdn_conv3x3_eval_cls(int dtype, const void* in0, int C0, const void* w, const float* ep_scale, const float* ep_shift, void* act_out,
+                                    const float* cls_w, const float* cls_b, int ncls, float* logits, uint8_t* mask, const int32_t* origins,
+                                    int Hs, int Ws, int N, int H, int W, int Cout, void* stream) {
+    if (!cls_w) BDN_FAIL(BDN_E_ARG, "conv3x3_eval_cls: null pointer");
+    return conv3x3_eval_impl(dtype, in0, C0, nullptr, 0, w, ep_scale, ep_shift, act_out, nullptr, nullptr, cls_w, cls_b, ncls, logits, mask, origins,
+                             Hs, Ws, N, H, W, Cout, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 3x3x3 convolution, stride 1, zero padding 1 in depth / height / width -- the building block of BASELINE configs[3], the
 // multi-date 3-D U-Net (5 dates x 13 bands x 128 x 128).  The reference tree has NO source for that model (UNetLSTM/ is an
@@ -769,6 +1005,9 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     a.imgs_per_group = imgs_per_group * D;
     a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial; a.bs_z = nullptr; a.bs_bn = nullptr;
     a.N = N * D; a.H = H; a.W = W; a.Cout = Cout;
+    a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
     const ConvPlan p = conv3d_plan(N * D, H, W, Cout);
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

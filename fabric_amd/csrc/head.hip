@@ -199,15 +199,7 @@ constexpr int OUTC_BWD_ITERS = 32;  // ... and backward: every block ends with 1
 // partial dot products of a pixel meet in its first lane by DPP row shifts (same association as the xor butterfly: 4, 2, 1 -- the
 // same bits) instead of ds_bpermute round trips in a run-time loop, and the next four pixels of a lane are requested before the
 // current four are reduced (round 5: 42 -> 3x us at B = 64).
-template <int N> __device__ __forceinline__ float dpp_row_shl(float v) {     // lane i <- lane i + N of its row of 16 (0 beyond the row)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
-}
-template <int CU> __device__ __forceinline__ float first_lane_sum(float v) {
-    static_assert(CU == 8 || CU == 16, "lanes per pixel");
-    if constexpr (CU == 16) v += dpp_row_shl<8>(v);
-    v += dpp_row_shl<4>(v); v += dpp_row_shl<2>(v); v += dpp_row_shl<1>(v);
-    return v;
-}
+// (dpp_row_shl / first_lane_sum: common.hpp -- the eval-mode convolution epilogue sums a pixel's classifier terms the same way)
 template <typename T, int NC, int CUC = 0>
 __global__ __launch_bounds__(256) void outc_fwd_kernel(const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ w,
                                 const float* __restrict__ bias, float* __restrict__ logits, int npix, int hw, int C, int ncls, FastDiv dhw) {

@@ -229,6 +229,11 @@ class BiDateEngine:
         self._packed_valid = False
         self._pack_desc = None
         self._packed_versions = None
+        self._ev = None            # eval-mode tables: (parameter pointers, device descriptor, {layer: (scale, shift)}, identity BatchNorm table)
+        # eval_fused: model.eval() forwards in the bf16 / fp32 settings run the eval-shaped schedule (_forward_eval: one launch per
+        # conv -> BatchNorm -> ReLU stage, date product / pooling / classifier in the epilogues); False = the training kernels on a
+        # running-statistics table (the round 1-5 path, kept for A/B and as the checker of the new one in tests)
+        self.eval_fused = True
         # The only tuning attributes (tools/archive/ab_flag.py A/Bs them in one process).  Everything round 1 and 2 measured and lost -- the
         # unfused BatchNorm-backward paths, relu(bn(z)) materialised for the weight gradient, the two-pass encoder skip backward,
         # release schedules of the weight-gradient GEMMs -- is gone from the product (DESIGN.md section 4 keeps the findings,
@@ -267,9 +272,9 @@ class BiDateEngine:
         return _lib.load().bdn_conv3x3_variant(self.mdt, n, h, w, c0 + c1 if self.x3 else c0, 0 if self.x3 else c1, cout, ipg).decode()
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3', bb=False):
-        name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg) if self.prof is not None else None
-        if name is not None and bb:                 # BatchNorm-backward-on-load launches: the same tile configuration, template flag BB set
-            name = name[:name.rindex(',')] + ',true>'
+        name = None
+        if self.prof is not None:                   # BatchNorm-backward-on-load launches have their own dispatcher: ask it
+            name = _lib.load().bdn_conv3x3_dgrad_bb_variant(n, h, w, cout, ipg).decode() if bb else self.conv_kernel_name(n, h, w, c0, c1, cout, ipg)
         if self.prof is None or (self.prof_filter is not None and name not in self.prof_filter):
             call(fn, *args)
             return
@@ -407,9 +412,11 @@ class BiDateEngine:
         return z, bn
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x_d1, x_d2, P, training=True):
+    def forward(self, x_d1, x_d2, P, training=True, class_map=False):
         """x_d1, x_d2: [B,C,H,W] float32 CUDA tensors (reference layout).  P: state-dict-keyed tensors.
-        Returns (logits [B,n_classes,H,W] float32, workspace)."""
+        Returns (logits [B,n_classes,H,W] float32, workspace).  class_map=True (eval mode only): returns the uint8 [B,H,W] map
+        torch.max(logits, 1)[1] (train.py:199) instead of the logits -- on the eval-shaped schedule it comes straight out of the last
+        convolution's epilogue."""
         self._prof_seen = 0
         if not (x_d1.is_cuda and x_d2.is_cuda):
             raise RuntimeError('fabric_amd: BiDateNet runs only on a ROCm device (MI355X); '
@@ -422,13 +429,25 @@ class BiDateEngine:
         ws = self.workspace(B, H, W, x_d1.device)
         ws.generation += 1
         call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, _lib.stream_ptr())
+        if class_map:
+            if training:
+                raise RuntimeError('class_map=True is an eval-mode output')
+            cd = torch.empty(B, H, W, dtype=torch.uint8, device=x_d1.device)
+            if self._use_eval_schedule():
+                self._forward_eval(ws, P, mask=cd)
+            else:
+                logits = self._forward_packed(ws, P, False)
+                call('bdn_argmax', ptr(logits), ptr(cd), B, self.n_classes, H, W, _lib.stream_ptr())
+            return cd, ws
         return self._forward_packed(ws, P, training), ws
 
-    def forward_tiles(self, scene_d1, scene_d2, origins, P, patch_size, reuse_eval_bn=False, slot=0):
+    def forward_tiles(self, scene_d1, scene_d2, origins, P, patch_size, reuse_eval_bn=False, slot=0, scene_mask=None):
         """Eval-mode forward of the tiles at `origins` (device int32 [n,2] = (y0,x0)) of a scene whose two dates
         are resident as [C,H,W] float32 band planes (train.py:190-197 without the host-side patch stack).
-        reuse_eval_bn: the BatchNorm tables of this workspace are already those of P's running statistics.
-        Returns (logits [n,n_classes,p,p] float32, workspace)."""
+        reuse_eval_bn: the BatchNorm tables of this workspace (eval-shaped schedule: of the engine) are already those of P's running statistics.
+        scene_mask: uint8 [H,W] device tensor -- the class index of every pixel of these tiles is written straight into it
+        (utils/inference.py:187-236 ownership rule) and no logits are returned.
+        Returns (logits [n,n_classes,p,p] float32 or None, workspace)."""
         if not (scene_d1.is_cuda and scene_d2.is_cuda and origins.is_cuda):
             raise RuntimeError('fabric_amd: scene planes and tile origins must be CUDA/HIP tensors -- there is no CPU path')
         if scene_d1.shape != scene_d2.shape or scene_d1.dim() != 3 or scene_d1.shape[0] != self.n_channels:
@@ -443,6 +462,15 @@ class BiDateEngine:
         ws.generation += 1
         call('bdn_gather_tiles', self.dt, ptr(scene_d1), ptr(scene_d2), ptr(origins), ptr(ws.x0),
              n, C, H, W, p, self.cp, _lib.stream_ptr())
+        if scene_mask is not None:
+            if scene_mask.dtype != torch.uint8 or tuple(scene_mask.shape) != (H, W) or not scene_mask.is_contiguous() or not scene_mask.is_cuda:
+                raise RuntimeError(f'scene_mask must be a contiguous uint8 [{H},{W}] device tensor')
+            if self._use_eval_schedule():
+                self._forward_eval(ws, P, reuse_tables=reuse_eval_bn, mask=scene_mask, origins=origins, scene_hw=(H, W))
+            else:
+                logits = self._forward_packed(ws, P, False, reuse_eval_bn)
+                call('bdn_argmax_stitch', ptr(logits), ptr(origins), ptr(scene_mask), n, logits.shape[1], p, H, W, _lib.stream_ptr())
+            return None, ws
         return self._forward_packed(ws, P, False, reuse_eval_bn), ws
 
     def _forward_packed(self, ws, P, training, reuse_eval_bn=False):
@@ -458,6 +486,8 @@ class BiDateEngine:
             # In-place writes through `p.data` (p.data.copy_(ema), p.data.clamp_()) bump NEITHER: call
             # invalidate_weights() after such an update (BiDateNet.load_state_dict / _apply do it themselves).
             self._packed_valid = False
+        if not training and self._use_eval_schedule():
+            return self._forward_eval(ws, P, reuse_tables=reuse_eval_bn)
         rb = reuse_eval_bn and not training
         k_first = 1
         if self.fwd_chains == 2 and training and not self.x3:
@@ -500,6 +530,100 @@ class BiDateEngine:
         logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)
         call('bdn_outc_fwd', self.dt, ptr(prev), ptr(prev_bn), ptr(P['outc.conv.weight']), ptr(P['outc.conv.bias']),
              ptr(logits), B, H, W, cprev, self.n_classes, st)
+        return logits
+
+    # ------------------------------------------------------------------ eval-shaped forward (round 6)
+    def _use_eval_schedule(self):
+        return self.eval_fused and not self.x3
+
+    def eval_tables(self, P):
+        """Eval-mode BatchNorm of all 18 layers folded with the conv biases (bdn_bn_eval_fold_multi: one launch on the current stream).
+        Returns {layer name: (scale [Cout], shift [Cout])}; the buffers are cached per parameter storage and REWRITTEN by every call
+        (running statistics move without a version bump)."""
+        import struct
+        keys = [(f'{L.bn}.weight', f'{L.bn}.bias', f'{L.bn}.running_mean', f'{L.bn}.running_var', f'{L.conv}.bias') for L in self.layers]
+        ptrs = tuple(P[k].data_ptr() for ks in keys for k in ks)
+        if self._ev is None or self._ev[0] != ptrs:
+            dev = P[keys[0][0]].device
+            tab = torch.empty(sum(2 * L.cout for L in self.layers), dtype=torch.float32, device=dev)
+            rec, views, off = b'', {}, 0
+            for L, ks in zip(self.layers, keys):
+                out = tab[off:off + 2 * L.cout]
+                off += 2 * L.cout
+                rec += struct.pack('<QQQQQQii', *(P[k].data_ptr() for k in ks), out.data_ptr(), L.cout, 0)
+                views[L.name] = (out[:L.cout], out[L.cout:])
+            ident = torch.zeros(1, 4, self.layers[-1].cout, dtype=torch.float32, device=dev)   # {mean 0, invstd 1, scale 1, shift 0}: relu(bn(a)) = a for a >= 0
+            ident[:, 1:3] = 1.0
+            self._ev = (ptrs, torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev), views, ident, tab)
+        call('bdn_bn_eval_fold_multi', ptr(self._ev[1]), len(self.layers), max(L.cout for L in self.layers), BN_EPS, _lib.stream_ptr())
+        return self._ev[2]
+
+    def _forward_eval(self, ws, P, reuse_tables=False, mask=None, origins=None, scene_hw=None):
+        """model.eval() forward on the packed input in ws.x0 (reference: train.py:125-172 validation, train.py:182-205 full-scene inference).
+        Nothing depends on batch statistics, so every conv -> BatchNorm -> ReLU stage is ONE launch whose epilogue applies the folded
+        running-statistics affine + ReLU and stores the ACTIVATION (bdn_conv3x3_eval): consumers stage plain bytes, there are no statistics
+        partials, no finalize / bn_eval launches.  The second convolution of an encoder level runs per date: date 1 stores its activation
+        and its pooled map, date 2 multiplies its own with date 1's in the copy-out (the skip relu(x_d2 * x_d1), models/bidate_model.py:35-38,
+        is what it stores -- its own activation never reaches HBM) and pools; product_pool / fuse_product launches are gone.  The last
+        decoder convolution carries the 1x1 classifier (and, for scene inference, argmax + stitching) in its epilogue.
+        Returns logits [B,n_classes,H,W] float32, or None when `mask` is given (uint8 [B,H,W], or the scene mask [Hs,Ws] with `origins`)."""
+        B, H, W = ws.B, ws.H, ws.W
+        dev = ws.x0.device
+        st = _lib.stream_ptr()
+        _lib.PHASE = 'fwd'
+        by = {L.name: L for L in self.layers}
+        if self._packed_valid and (self._packed_versions != tuple(P[f'{L.conv}.weight']._version for L in self.layers) or
+                                   self._pack_desc[0] != tuple(P[f'{L.conv}.weight'].data_ptr() for L in self.layers)):
+            self._packed_valid = False
+        ev = self._ev[2] if (reuse_tables and self._ev is not None) else self.eval_tables(P)
+
+        def stage(L, in0, c0, in1, c1, out, n, hk, wk, mul=None, pool=None):
+            wf, _ = self._weights(L, P, False)
+            sc, sh = ev[L.name]
+            call('bdn_conv3x3_eval', self.dt, ptr(in0), c0, ptr(in1), c1, ptr(wf), ptr(sc), ptr(sh), ptr(out), ptr(mul), ptr(pool),
+                 n, hk, wk, L.cout, st)
+
+        # ---- shared encoder: the first conv of a level on both dates at once, the second per date
+        for k in range(1, 6):
+            hk, wk = ws.dims[k - 1]
+            La, Lb = by[f'e{k}a'], by[f'e{k}b']
+            src = ws.x0 if k == 1 else ws.pool[k]
+            za, zb = ws.z[La.name], ws.z[Lb.name]
+            stage(La, src, La.cin, None, 0, za, 2 * B, hk, wk)
+            pn = ws.pool[k + 1] if k < 5 else None
+            stage(Lb, za[:B], Lb.cin, None, 0, zb[:B], B, hk, wk, pool=pn[:B] if k < 5 else None)
+            stage(Lb, za[B:], Lb.cin, None, 0, ws.f[k], B, hk, wk, mul=zb[:B], pool=pn[B:] if k < 5 else None)
+        # ---- decoder on the fused skips
+        prev, cprev = ws.f[5], ENC_CH[4]
+        logits = None
+        for j in range(1, 5):
+            k = 5 - j
+            hk, wk = ws.dims[k - 1]
+            hs, wsrc = ws.dims[k]
+            La, Lb = by[f'd{j}a'], by[f'd{j}b']
+            call('bdn_upsample2x', self.dt, ptr(prev), IN_PLAIN, None, ptr(ws.U[j]), B, hs, wsrc, hk, wk, cprev, st)
+            stage(La, ws.f[k], ENC_CH[k - 1], ws.U[j], cprev, ws.z[La.name], B, hk, wk)
+            if j < 4 or self.n_classes > 2:
+                stage(Lb, ws.z[La.name], Lb.cin, None, 0, ws.z[Lb.name], B, hk, wk)
+            else:
+                wf, _ = self._weights(Lb, P, False)
+                sc, sh = ev[Lb.name]
+                if mask is None:
+                    logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)
+                call('bdn_conv3x3_eval_cls', self.dt, ptr(ws.z[La.name]), Lb.cin, ptr(wf), ptr(sc), ptr(sh), None,
+                     ptr(P['outc.conv.weight']), ptr(P['outc.conv.bias']), self.n_classes, ptr(logits), ptr(mask), ptr(origins),
+                     scene_hw[0] if scene_hw else 0, scene_hw[1] if scene_hw else 0, B, hk, wk, Lb.cout, st)
+            prev, cprev = ws.z[Lb.name], Lb.cout
+        if self.n_classes > 2:                       # wider heads: the stand-alone classifier on the stored activation (identity BatchNorm table)
+            logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev)
+            call('bdn_outc_fwd', self.dt, ptr(prev), ptr(self._ev[3]), ptr(P['outc.conv.weight']), ptr(P['outc.conv.bias']),
+                 ptr(logits), B, H, W, cprev, self.n_classes, st)
+            if mask is not None:
+                if origins is not None:
+                    call('bdn_argmax_stitch', ptr(logits), ptr(origins), ptr(mask), B, self.n_classes, H, scene_hw[0], scene_hw[1], st)
+                else:
+                    call('bdn_argmax', ptr(logits), ptr(mask), B, self.n_classes, H, W, st)
+                return None
         return logits
 
     def _fwd_handoff(self, dev, i):
@@ -764,7 +888,7 @@ class BiDateEngine:
                      ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
                 call('bdn_outc_bn_bwd_apply', self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
                      ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dzb), B, hk, wk, Lb.cout, self.n_classes, st)
-            elif Lb.name in fold and rows_up and ldA == Lb.cout == 64:
+            elif Lb.name in fold and rows_up and ldA == Lb.cout == 64 and min(hk, wk) > 8:
                 dzb, dAa, rows = fold_dgrad(Lb, dA_ptr, B, B, rows_up, prev=La)
                 folded_b = True
             else:
@@ -772,7 +896,7 @@ class BiDateEngine:
             wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], B, B)
             if not folded_b:
                 dAa, rows = dgrad(Lb, dzb, B, B, prev=La)
-            if La.name in fold and La.cout == 64:
+            if La.name in fold and La.cout == 64 and min(hk, wk) > 8:     # (bdn_conv3x3_dgrad_bb refuses maps of 8x8 and below)
                 dza, dc = fold_dgrad(La, ptr(dAa), B, B, rows)
                 wgrad(La, dza, ws.f[k], ck, ws.U[j], cprev, IN_PLAIN, None, B, B)
             else:

@@ -21,8 +21,6 @@ from os import path
 import numpy as np
 import torch
 
-from .. import _lib
-from .._lib import call, ptr
 
 
 def get_path(path_list):
@@ -106,10 +104,7 @@ def predict_patches(model, patches1, patches2, batch_size, device='cuda'):
     for i in range(0, patches1.shape[0], batch_size):
         b1 = torch.from_numpy(np.ascontiguousarray(patches1[i:i + batch_size])).to(device)
         b2 = torch.from_numpy(np.ascontiguousarray(patches2[i:i + batch_size])).to(device)
-        logits, _ = eng.forward(b1, b2, P, training=False)
-        b, ncls, hh, ww = logits.shape
-        cd = torch.empty(b, hh, ww, dtype=torch.uint8, device=logits.device)
-        call('bdn_argmax', ptr(logits), ptr(cd), b, ncls, hh, ww, _lib.stream_ptr())
+        cd, _ = eng.forward(b1, b2, P, training=False, class_map=True)       # uint8 [b,p,p] = torch.max(preds, 1)[1]
         out.append(cd.cpu().numpy().astype(np.int64))
     return out
 
@@ -183,6 +178,9 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
     seen = [set() for _ in lanes]
     if len(lanes) > 1:
         eng._weights(eng.layers[0], P, False)            # the filter images are packed once, on the caller's stream, before the fork
+        if eng._use_eval_schedule():
+            eng.eval_tables(P)                           # and so are the folded BatchNorm tables both lanes read
+            seen = [{min(batch_size, hi - lo), (hi - lo) % batch_size or batch_size} for _ in lanes]
         for nb_ in {min(batch_size, hi - lo), (hi - lo) % batch_size or batch_size}:
             eng.workspace(nb_, patch_size, patch_size, dev, 1)             # second lane's buffers: allocated under the caller's stream
         lanes[1].wait_stream(cur)
@@ -197,10 +195,8 @@ def predict_scene(model, scene_d1, scene_d2, patch_size=128, batch_size=64, shar
             with torch.cuda.stream(lanes[k]):
                 if feed is not None:
                     feed.need_rows(int(o_np[i:j, 0].max()) + patch_size, lanes[k])     # this lane waits for the last band these tiles read
-                logits, _ = eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen[k], slot=k)
+                eng.forward_tiles(d1, d2, o, P, patch_size, reuse_eval_bn=nb in seen[k], slot=k, scene_mask=mask)
                 seen[k].add(nb)
-                call('bdn_argmax_stitch', ptr(logits), ptr(o), ptr(mask), nb, logits.shape[1], patch_size, h, w, lanes[k].cuda_stream)
-                logits.record_stream(lanes[k])
     finally:
         for ln in lanes[1:]:
             cur.wait_stream(ln)

@@ -115,6 +115,10 @@ int bdn_conv3x3_dgrad_bb(int dtype, const void* dA, int C0, const void* z, const
                          const void* w_dgrad, void* dA_prev, const void* z_prev, const float* bn_prev, float* bs_partial,
                          void* dz_out, int N, int H, int W, int Cout, void* stream);
 
+/* Name of the kernel instantiation bdn_conv3x3_dgrad_bb runs for a shape (its dispatcher picks its own tile configurations); "" for an
+ * unsupported shape.  Thread-local buffer, as bdn_conv3x3_variant. */
+const char* bdn_conv3x3_dgrad_bb_variant(int N, int H, int W, int Cout, int imgs_per_group);
+
 /* ---- 3x3x3 convolution, stride 1, zero padding 1 (BASELINE configs[3]: the multi-date 3-D U-Net stack) ----
  * The reference tree holds NO source for that model (UNetLSTM/ is an empty sub-module, README.md:5): parity is UNPINNED, the
  * oracle is torch.nn.functional.conv3d.  Implicit GEMM with K = 27 Cin on the 2-D kernels: tensors are [N,D,H,W,C] (the D
@@ -205,6 +209,33 @@ int bdn_bn_finalize(const float* stats_partial, int n_mtiles, int G, int C, int 
 /* Eval mode: bn[0][..] from the running buffers (mean=rm, invstd=rsqrt(rv+eps)), replicated for G groups. */
 int bdn_bn_eval(const float* gamma, const float* beta, const float* running_mean,
                 const float* running_var, float eps, int G, int C, float* bn, void* stream);
+
+/* ---- eval-mode stages (round 6): nothing depends on batch statistics, so conv -> BatchNorm -> ReLU is ONE launch ----
+ * Reference: model.eval() forward of double_conv, models/unet_parts.py:13-18, as validation (train.py:125-172) and full-scene
+ * inference (train.py:182-205, utils/inference.py:134-236) run it.
+ *
+ * bdn_bn_eval_fold_multi: per layer  scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale  (bdn_bn_eval's values),
+ *   out[0][c] = scale, out[1][c] = conv_bias[c] * scale + shift, for n_layers layers in one launch.  desc: DEVICE array of records
+ *   { const float* gamma, *beta, *running_mean, *running_var, *conv_bias (may be NULL); float* out (= [2][C] floats); int32 C, reserved; }
+ *   (56 bytes each); max_C = the largest C among them.
+ *
+ * bdn_conv3x3_eval: out = relu(conv3x3(in0 | in1) * ep_scale + ep_shift) as [N,H,W,Cout]; operands are PLAIN activations (what such a
+ *   launch stores), w the bdn_pack_weights forward image.  Optional fused consumers (either may be NULL):
+ *     mul  [N,H,W,Cout]     the other date's activation of the same layer: `out` then receives relu(x_d2 * x_d1) = a * mul
+ *                           (models/bidate_model.py:35-38; both factors are rounded activations >= 0) instead of a;
+ *     pool [N,H/2,W/2,Cout] nn.MaxPool2d(2) of a (models/unet_parts.py:40, floor mode).
+ * bdn_conv3x3_eval_cls: the last double_conv stage (Cout = 64) with the 1x1 classifier (models/unet_parts.py:88-89, ncls <= 2) in its
+ *   epilogue: logits [N,ncls,H,W] f32 (NULL: not stored; bit-identical to bdn_outc_fwd on the stored activation), mask = argmax over
+ *   classes (first maximum wins, train.py:199) as uint8 -- [N,H,W] when origins is NULL, else stitched into the scene mask [Hs,Ws] at
+ *   origins[n] = (y0, x0) with bdn_argmax_stitch's ownership rule (utils/inference.py:187-236).  act_out (NULL: not stored) = the activation.
+ * dtype BDN_BF16 or BDN_F32.  Every tensor below 4 GB. */
+int bdn_bn_eval_fold_multi(const void* desc, int n_layers, int max_C, float eps, void* stream);
+int bdn_conv3x3_eval(int dtype, const void* in0, int C0, const void* in1, int C1, const void* w,
+                     const float* ep_scale, const float* ep_shift, void* out, const void* mul, void* pool,
+                     int N, int H, int W, int Cout, void* stream);
+int bdn_conv3x3_eval_cls(int dtype, const void* in0, int C0, const void* w, const float* ep_scale, const float* ep_shift, void* act_out,
+                         const float* cls_w, const float* cls_b, int ncls, float* logits, uint8_t* mask, const int32_t* origins,
+                         int Hs, int Ws, int N, int H, int W, int Cout, void* stream);
 
 /* ---- BatchNorm2d + ReLU backward (autograd of models/unet_parts.py:14-15,17-18) ----
  * g = dA * [z*scale+shift > 0]; sums[g][0][c] = sum g, sums[g][1][c] = sum g*xhat (layout [G][2][C]);

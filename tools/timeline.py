@@ -1,15 +1,16 @@
 """Per-step timeline of the two streams from a rocprofv3 --kernel-trace CSV (test infrastructure).
-    python tools/timeline.py <kernel_trace.csv> [step_index_from_end=2]
-Splits the trace into steps at pack_input_kernel launches, then prints for one step every kernel with its queue, start
+    python tools/timeline.py <kernel_trace.csv> [step_index_from_end=2] [marker=pack_input_kernel]
+Splits the trace into steps at launches of the marker kernel (scene inference: gather_tiles_kernel), then prints for one step every kernel with its queue, start
 offset, duration, and the idle gap since the previous kernel of the SAME queue; plus per-queue busy time and union busy time."""
 import csv, sys, collections
 path = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+marker = sys.argv[3] if len(sys.argv) > 3 else 'pack_input_kernel'
 rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', '0'), r['Kernel_Name'].split('(')[0].replace('void ', '')))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[3].startswith('pack_input_kernel')]
+starts = [i for i, r in enumerate(rows) if r[3].startswith(marker)]
 i0, i1 = starts[-which - 1], starts[-which]
 step = rows[i0:i1]
 t0 = step[0][0]
