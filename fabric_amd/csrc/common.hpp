@@ -172,6 +172,20 @@ template <int CU> __device__ __forceinline__ float first_lane_sum(float v) {
     return v;
 }
 
+// element-wise maximum of two 16-byte units of NON-NEGATIVE values (post-ReLU activations): for bf16 the order of non-negative values is the
+// order of their bit patterns as signed 16-bit integers (a -0.0 = 0x8000 is the smallest), so four v_pk_max_i16 do it without unpacking
+template <typename T> __device__ __forceinline__ uint4 unit_max_nonneg(const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ uint4 unit_max_nonneg<float>(const uint4& a, const uint4& b) {
+    return make_uint4(__float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))), __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y))),
+                      __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))), __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w))));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+template <> __device__ __forceinline__ uint4 unit_max_nonneg<bf16s>(const uint4& a, const uint4& b) {
+    return make_uint4(pk_max_i16(a.x, b.x), pk_max_i16(a.y, b.y), pk_max_i16(a.z, b.z), pk_max_i16(a.w, b.w));
+}
+
 // Filter image in MFMA fragment order (what conv3x3_kernel streams from L2): one contiguous 1 KB record per
 // (32 output channels, tap, k-group of 32 bytes of input channels); inside a record lane l owns 16 bytes:
 // output channel 32*cb + (l & 31), input channels kgroup*KCH + (l >> 5)*EPU + [0, EPU).

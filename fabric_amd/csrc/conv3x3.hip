@@ -19,6 +19,7 @@
 // Epilogue: + bias, per-tile sum / sum^2 for the following BatchNorm, transpose through LDS, 16-byte
 // coalesced NHWC stores.  Block ids are remapped so the N-tiles of one M-tile share an XCD's L2.
 #include "common.hpp"
+#include <type_traits>
 
 struct ConvArgs {
     const void* in0; const void* in1; int C0, C1;
@@ -57,7 +58,11 @@ struct ConvArgs {
     //   ep_pool  [N,H/2,W/2,Cout]  nn.MaxPool2d(2) of a (models/unet_parts.py:40; floor mode), from the tile in LDS;
     //   cls_*    the 1x1 classifier (models/unet_parts.py:88-89) on a tile that holds all Cout = 64 channels: logits [N,ncls,H,W] f32 and / or
     //            the class index (first maximum wins, train.py:199) as a [N,H,W] map or stitched into a scene mask (utils/inference.py:187-236).
-    const float* ep_scale; const float* ep_shift; const void* ep_mul; void* ep_pool;
+    //   pair_stride > 0 (bdn_conv3x3_eval_pair; two-image tile configurations only): the two images of a tile are n and n + pair_stride -- the
+    //            two DATES of one patch pair (N = 2 pair_stride) -- instead of two consecutive ones.  The block then holds both dates'
+    //            activations of its pixels in LDS: `out` [pair_stride,H,W,Cout] receives their product, ep_pool [N,H/2,W/2,Cout] both pooled
+    //            maps, and neither date's activation reaches HBM.
+    const float* ep_scale; const float* ep_shift; const void* ep_mul; void* ep_pool; int pair_stride;
     const float* cls_w; const float* cls_b; int cls_n; float* cls_logits; unsigned char* cls_mask; const int* cls_origins; int cls_H, cls_W;
 };
 
@@ -142,7 +147,9 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = logical % a.n_ntiles, mtile = logical / a.n_ntiles;   // block-uniform scalar divisions (shifts for power-of-two grids measured no faster)
     const int tx = mtile % a.tiles_x, ty = (mtile / a.tiles_x) % a.tiles_y, ib = mtile / (a.tiles_x * a.tiles_y);
-    const int n0 = ib * TI, y0 = ty * TH, x0 = tx * TW, col0 = ntile * BN;
+    const bool paired = EV && TI == 2 && a.pair_stride > 0;                   // block-uniform (eval-mode date-paired tiles)
+    const int istr = paired ? a.pair_stride : 1;                              // image stride between the tile's images
+    const int n0 = paired ? ib : ib * TI, y0 = ty * TH, x0 = tx * TW, col0 = ntile * BN;
     const int Cin = D3 ? 3 * a.C0 : a.C0 + a.C1;
     const int grp = n0 / a.imgs_per_group;
     // 3x3x3 mode: which of the three depth sources exist for this tile's slice (bit s: slice d + s - 1 lies inside the sample)
@@ -150,6 +157,9 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     const unsigned dmask = D3 ? ((dslice > 0 ? 1u : 0u) | 2u | (dslice + 1 < a.Dz ? 4u : 0u)) : 7u;
     static_assert(!D3 || TI == 1, "a 3x3x3 tile belongs to one depth slice");
 
+    // eval-mode single-chunk kernels (the full-resolution 64-channel layers: instruction-issue bound, 14.8 instructions per MFMA of which
+    // three quarters are prologue and epilogue): tiles whose halo lies inside the image take a prologue without bounds tests / zero fill
+    const bool interior = EV && ONE && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= a.H && x0 + TW + 1 <= a.W && n0 + (TI - 1) * istr < a.N;
     // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
     int p_pix[NPU];                                      // global pixel index of each unit (-1 = zero padding)
     {
@@ -160,15 +170,26 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         constexpr int YWRAPS = (DY + 1) / TL::PH + 1;        // upper bound on row wraps per step
         const int pix0 = tid / UPP;
         int xx = pix0 % TL::PW, t0 = pix0 / TL::PW, yy = t0 % TL::PH, ti = t0 / TL::PH;
+        if (interior) {                                      // (block-uniform) every patch pixel lies inside the image: no per-unit tests
 #pragma unroll
-        for (int i = 0; i < NPU; i++) {
-            const int n = n0 + ti, y = y0 + yy - 1, x = x0 + xx - 1;
-            const bool ok = ti < TI && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
-            xx += DX; yy += DY;
-            if (xx >= TL::PW) { xx -= TL::PW; yy += 1; }
+            for (int i = 0; i < NPU; i++) {
+                p_pix[i] = ti < TI ? ((n0 + ti * istr) * a.H + y0 + yy - 1) * a.W + x0 + xx - 1 : 0;      // ti == TI: the tail units behind the patch
+                xx += DX; yy += DY;
+                if (xx >= TL::PW) { xx -= TL::PW; yy += 1; }
 #pragma unroll
-            for (int k = 0; k < YWRAPS; k++) if (yy >= TL::PH) { yy -= TL::PH; ti += 1; }
+                for (int k = 0; k < YWRAPS; k++) if (yy >= TL::PH) { yy -= TL::PH; ti += 1; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPU; i++) {
+                const int n = n0 + ti * istr, y = y0 + yy - 1, x = x0 + xx - 1;
+                const bool ok = ti < TI && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                p_pix[i] = ok ? (n * a.H + y) * a.W + x : -1;
+                xx += DX; yy += DY;
+                if (xx >= TL::PW) { xx -= TL::PW; yy += 1; }
+#pragma unroll
+                for (int k = 0; k < YWRAPS; k++) if (yy >= TL::PH) { yy -= TL::PH; ti += 1; }
+            }
         }
     }
     const int p_sub = (tid % UPP) * EPU;                 // channel offset of this thread's units (256 % UPP == 0)
@@ -264,7 +285,12 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
 
     // the first patch is requested before anything else is computed: the rest of the prologue (LDS offsets, accumulator
     // clear, filter addressing) runs in the shadow of its HBM latency
-    LOAD_PATCH(0)
+    if (EV && ONE && interior) {
+        const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(a.in0);
+        const unsigned cb_ = (unsigned)a.ld0 * CF::ES;
+#pragma unroll
+        for (int i = 0; i < NPU; i++) preg[i] = *reinterpret_cast<const uint4*>(sb_ + ((unsigned)p_pix[i] * cb_ + p_subb));
+    } else LOAD_PATCH(0)
 
     int a_off[MI];                                       // per-lane LDS offsets of the A rows (pixel slots)
 #pragma unroll
@@ -359,11 +385,19 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     // prologue: first patch -> LDS buffer 0, steps 0 and 1 -> ring slots 0 and 1
     LOAD_R(r0, 0, 0)
     LOAD_R(r1, 1, 0)
-    STORE_PATCH(0, 0)
+    if (EV && ONE && interior) {
+#pragma unroll
+        for (int i = 0; i < NPU; i++) {
+            const int u_ = tid + i * 256, pix_ = u_ / UPP, xx_ = pix_ % TL::PW, t_ = pix_ / TL::PW;
+            if ((i + 1) * 256 <= TL::NPIX * UPP || u_ < TL::NPIX * UPP)
+                *reinterpret_cast<uint4*>(smem + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = preg[i];
+        }
+    } else STORE_PATCH(0, 0)
     __syncthreads();
 
     int chunk = 0;
-    for (int c0 = 0; c0 < Cin; c0 += CK, chunk++) {
+    // (eval-mode single-chunk kernels: the trip count is spelled as a constant, so the accumulator clear folds into the first MFMAs' C operand)
+    for (int c0 = 0; (EV && ONE) ? c0 < CK : c0 < Cin; c0 += CK, chunk++) {
         const unsigned char* pcur = smem + (PBUF == 2 ? (chunk & 1) : 0) * CF::PATCH_BYTES;
         const bool more = ONE ? false : (c0 + CK < Cin);
         const int rec0 = chunk * KG;                     // record offset of this chunk inside a (cout block, tap) row
@@ -399,18 +433,28 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)col0 * CF::OES;
         const unsigned char* mulp = reinterpret_cast<const unsigned char*>(a.ep_mul) + (size_t)col0 * CF::OES;
         const bool has_mul = a.ep_mul != nullptr, has_out = a.out != nullptr;       // block-uniform
+        const bool full = (n0 + (TI - 1) * istr < a.N) && (y0 + TH <= a.H) && (x0 + TW <= a.W);          // block-uniform
 #define OUT_OFS(i_, dst_)                                   /* byte offset of copy-out unit i_ in the output tensor, ~0 = outside the image */ \
         {                                                                                               \
             const int u_ = tid + (i_) * 256, slot_ = u_ / UPR, sub_ = u_ % UPR;                         \
             int ti_, py_, px_; TL::slot_to_nyx(slot_, ti_, py_, px_);                                   \
-            const int n_ = n0 + ti_, y_ = y0 + py_, x_ = x0 + px_;                                      \
-            dst_ = (n_ < a.N && y_ < a.H && x_ < a.W) ? (unsigned)((n_ * a.H + y_) * a.W + x_) * orow + (unsigned)sub_ * 16u : 0xffffffffu; \
+            const int n_ = n0 + ti_ * istr, y_ = y0 + py_, x_ = x0 + px_;                                      \
+            dst_ = (full || (n_ < a.N && y_ < a.H && x_ < a.W)) ? (unsigned)((n_ * a.H + y_) * a.W + x_) * orow + (unsigned)sub_ * 16u : 0xffffffffu; \
         }
         unsigned oofs[NPRE];
         uint4 mq[NPRE];
-        if (PRE) {
+        if (PRE && !paired && a.cls_w == nullptr) {
+            if (full) {                                      // (block-uniform: the same offsets without the per-unit bounds tests)
 #pragma unroll
-            for (int i = 0; i < NPRE; i++) OUT_OFS(i, oofs[i])
+                for (int i = 0; i < NPRE; i++) {
+                    const int u_ = tid + i * 256, slot_ = u_ / UPR, sub_ = u_ % UPR;
+                    int ti_, py_, px_; TL::slot_to_nyx(slot_, ti_, py_, px_);
+                    oofs[i] = (unsigned)(((n0 + ti_ * istr) * a.H + y0 + py_) * a.W + x0 + px_) * orow + (unsigned)sub_ * 16u;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPRE; i++) OUT_OFS(i, oofs[i])
+            }
             if (has_mul) {                                   // the other date's units: requested a whole accumulator pass ahead of their use
 #pragma unroll
                 for (int i = 0; i < NPRE; i++) mq[i] = *reinterpret_cast<const uint4*>(mulp + (oofs[i] != 0xffffffffu ? oofs[i] : 0u));
@@ -452,7 +496,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
                 for (int i = 0; i < NIT; i++) {
                     const int u_ = tid + i * 256, slot_ = u_ / UPR;
                     int ti_, py_, px_; TL::slot_to_nyx(slot_, ti_, py_, px_);
-                    const int n_ = n0 + ti_, y_ = y0 + py_, x_ = x0 + px_;
+                    const int n_ = n0 + ti_ * istr, y_ = y0 + py_, x_ = x0 + px_;
                     const bool in_ = n_ < a.N && y_ < a.H && x_ < a.W;
                     const uint4 v = *reinterpret_cast<const uint4*>(otile + slot_ * CF::OSTR + (u_ % UPR) * 16);
                     float f[OEPU], l0 = 0.f, l1 = 0.f;
@@ -485,6 +529,31 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
             }
             return;
         }
+        if (paired) {
+            // date-paired tile: slots [0, TH*TW) hold date 1, [TH*TW, 2 TH*TW) date 2 of the same pixels -- the skip relu(x_d2 * x_d1) is formed
+            // from LDS (both factors rounded activations, as fuse_product_kernel forms it) and is the only full-resolution tensor stored
+            constexpr int HALF = TH * TW, NF = (HALF * UPR + 255) / 256;
+            auto product = [&](auto full_c) {                 // full tiles (block-uniform) carry no per-unit bounds tests
+                constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+                for (int i = 0; i < NF; i++) {
+                    const int u_ = tid + i * 256, slot_ = u_ / UPR, sub_ = u_ % UPR;
+                    const int py_ = slot_ / TW, px_ = slot_ % TW, y_ = y0 + py_, x_ = x0 + px_;
+                    if ((HALF * UPR) % 256 == 0 || u_ < HALF * UPR) {
+                        if (FULL || (y_ < a.H && x_ < a.W)) {
+                            float fa[OEPU], fb[OEPU];
+                            Unit<TO>::unpack(*reinterpret_cast<const uint4*>(otile + slot_ * CF::OSTR + sub_ * 16), fa);
+                            Unit<TO>::unpack(*reinterpret_cast<const uint4*>(otile + (slot_ + HALF) * CF::OSTR + sub_ * 16), fb);
+#pragma unroll
+                            for (int e = 0; e < OEPU; e++) fa[e] *= fb[e];
+                            *reinterpret_cast<uint4*>(outp + ((unsigned)((n0 * a.H + y_) * a.W + x_) * orow + (unsigned)sub_ * 16u)) = Unit<TO>::pack(fa);
+                        }
+                    }
+                }
+            };
+            if (full) product(std::true_type{}); else product(std::false_type{});
+        } else
+        {
         // copy-out: 16-byte NHWC units; with ep_mul what leaves is the date product (both factors rounded activations, as fuse_product_kernel forms it)
 #define COPY_UNIT(i_, o_, mexpr_)                                                                        \
         if ((o_) != 0xffffffffu) {                                                                      \
@@ -512,33 +581,32 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         }
 #undef COPY_UNIT
 #undef OUT_OFS
+        }
         if (a.ep_pool != nullptr) {
             // MaxPool2d(2) of the tile's own activation (still in LDS, untouched by the product above): tiles start on even rows / columns,
             // so every 2x2 window lies inside one tile; floor mode drops the window of a trailing odd row / column
             constexpr int PHT = TH / 2, PWT = TW / 2, NPP = TI * PHT * PWT * UPR;
             const int Ho = a.H / 2, Wo = a.W / 2;
             unsigned char* poolp = reinterpret_cast<unsigned char*>(a.ep_pool) + (size_t)col0 * CF::OES;
+            auto pooling = [&](auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-            for (int i = 0; i < (NPP + 255) / 256; i++) {
-                const int u_ = tid + i * 256, pp_ = u_ / UPR, sub_ = u_ % UPR;
-                const int ti_ = pp_ / (PHT * PWT), r_ = pp_ % (PHT * PWT), py_ = r_ / PWT, px_ = r_ % PWT;
-                const int n_ = n0 + ti_, yo_ = y0 / 2 + py_, xo_ = x0 / 2 + px_;
-                if (u_ < NPP && n_ < a.N && yo_ < Ho && xo_ < Wo) {
-                    const unsigned char* w00 = otile + ((ti_ * TH + 2 * py_) * TW + 2 * px_) * CF::OSTR + sub_ * 16;
-                    float m[OEPU], f[OEPU];
-                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00), m);
-                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00 + CF::OSTR), f);
-#pragma unroll
-                    for (int e = 0; e < OEPU; e++) m[e] = fmaxf(m[e], f[e]);
-                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00 + TW * CF::OSTR), f);
-#pragma unroll
-                    for (int e = 0; e < OEPU; e++) m[e] = fmaxf(m[e], f[e]);
-                    Unit<TO>::unpack(*reinterpret_cast<const uint4*>(w00 + (TW + 1) * CF::OSTR), f);
-#pragma unroll
-                    for (int e = 0; e < OEPU; e++) m[e] = fmaxf(m[e], f[e]);
-                    *reinterpret_cast<uint4*>(poolp + ((unsigned)((n_ * Ho + yo_) * Wo + xo_) * orow + (unsigned)sub_ * 16u)) = Unit<TO>::pack(m);
+                for (int i = 0; i < (NPP + 255) / 256; i++) {
+                    const int u_ = tid + i * 256, pp_ = u_ / UPR, sub_ = u_ % UPR;
+                    const int ti_ = pp_ / (PHT * PWT), r_ = pp_ % (PHT * PWT), py_ = r_ / PWT, px_ = r_ % PWT;
+                    const int n_ = n0 + ti_ * istr, yo_ = y0 / 2 + py_, xo_ = x0 / 2 + px_;
+                    if (NPP % 256 == 0 || u_ < NPP) {
+                        if (FULL || (n_ < a.N && yo_ < Ho && xo_ < Wo)) {
+                            const unsigned char* w00 = otile + ((ti_ * TH + 2 * py_) * TW + 2 * px_) * CF::OSTR + sub_ * 16;
+                            const uint4 m = unit_max_nonneg<TO>(unit_max_nonneg<TO>(*reinterpret_cast<const uint4*>(w00), *reinterpret_cast<const uint4*>(w00 + CF::OSTR)),
+                                                                unit_max_nonneg<TO>(*reinterpret_cast<const uint4*>(w00 + TW * CF::OSTR),
+                                                                                    *reinterpret_cast<const uint4*>(w00 + (TW + 1) * CF::OSTR)));
+                            *reinterpret_cast<uint4*>(poolp + ((unsigned)((n_ * Ho + yo_) * Wo + xo_) * orow + (unsigned)sub_ * 16u)) = m;
+                        }
+                    }
                 }
-            }
+            };
+            if (full) pooling(std::true_type{}); else pooling(std::false_type{});
         }
         return;
     }
@@ -816,7 +884,7 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.bs_z = bs_z; a.bs_bn = bs_bn; a.in2 = nullptr; a.Dz = 0;
     a.bb_z = bb_z; a.bb_bn = bb_bn; a.bb_sums = bb_sums; a.bb_dz = bb_dz; a.bb_invM = 1.f / (float)((size_t)imgs_per_group * H * W);
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
-    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
     a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
     const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
@@ -920,7 +988,7 @@ static int conv3x3_eval_impl(int dtype, const void* in0, int C0, const void* in1
     a.in_bn = nullptr; a.imgs_per_group = N; a.w = w; a.w_kgroups = 0; a.bias = nullptr; a.out = out; a.stats_partial = nullptr;
     a.bs_z = nullptr; a.bs_bn = nullptr; a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
-    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mul = mul; a.ep_pool = pool;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mul = mul; a.ep_pool = pool; a.pair_stride = 0;
     a.cls_w = cls_w; a.cls_b = cls_b; a.cls_n = ncls; a.cls_logits = logits; a.cls_mask = mask; a.cls_origins = origins; a.cls_H = Hs; a.cls_W = Ws;
     // no statistic groups in eval mode: two images of a small map may always share a tile
     const ConvPlan g = conv_plan(N, H, W, Cout, N % 2 == 0 ? 2 : 1);
@@ -941,6 +1009,58 @@ extern "C" int bdn_conv3x3_eval(int dtype, const void* in0, int C0, const void* 
                                 int N, int H, int W, int Cout, void* stream) {
     return conv3x3_eval_impl(dtype, in0, C0, in1, C1, w, ep_scale, ep_shift, out, mul, pool, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0,
                              N, H, W, Cout, stream);
+}
+
+// Date-paired eval stage: the second convolution of an encoder level on BOTH dates of B patch pairs (in [2B,H,W,C0], date 1 first) with tiles
+// of two images n and n + B.  f_out [B,H,W,Cout] = relu(a_d2 * a_d1) (models/bidate_model.py:35-38), pool [2B,H/2,W/2,Cout] = MaxPool2d(2) of
+// both dates (NULL at the last level); the activations themselves are never stored.
+static ConvPlan conv_plan_pair(int B, int H, int W, int Cout) {
+    ConvPlan p;
+    TileGeom& g = p.g;
+    const bool narrow = (Cout % 128 != 0);
+    g.TI = 2; g.TH = 8;
+    g.TW = (!(W <= 8 && H <= 8) && narrow) ? 16 : 8;
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    g.n_mtiles = B * g.tiles_y * g.tiles_x;
+    p.BN = (!narrow && (long)g.n_mtiles * (Cout / 128) >= 512) ? 128 : 64;
+    return p;
+}
+
+template <typename T>
+static int dispatch_conv_pair(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+    const TileGeom& g = p.g;
+    const bool one = a.C0 * (int)sizeof(T) == 128;
+    if (g.TW == 16 && one) return launch_conv<T, 128, 8, 16, 2, 64, 2, 2, true, T, false, false, true>(a, g.n_mtiles, st);
+    if (g.TW == 16) return launch_conv<T, 128, 8, 16, 2, 64, 4, 1, false, T, false, false, true>(a, g.n_mtiles, st);
+    if (p.BN == 128 && (a.H > 8 || a.W > 8)) return launch_conv<T, 128, 8, 8, 2, 128, 1, 4, false, T, false, false, true>(a, g.n_mtiles, st);
+    if (p.BN == 128) return launch_conv<T, 128, 8, 8, 2, 128, 2, 2, false, T, false, false, true>(a, g.n_mtiles, st);
+    return launch_conv<T, 128, 8, 8, 2, 64, 2, 2, false, T, false, false, true>(a, g.n_mtiles, st);
+}
+
+extern "C" int bdn_conv3x3_eval_pair(int dtype, const void* in, int C0, const void* w, const float* ep_scale, const float* ep_shift,
+                                     void* f_out, void* pool, int B, int H, int W, int Cout, void* stream) {
+    if (!in || !w || !ep_scale || !ep_shift || !f_out) BDN_FAIL(BDN_E_ARG, "conv3x3_eval_pair: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_pair: bad B=%d H=%d W=%d", B, H, W);
+    if (Cout <= 0 || Cout % 64) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_pair: Cout=%d must be a multiple of 64", Cout);
+    if (dtype != BDN_BF16 && dtype != BDN_F32) BDN_FAIL(BDN_E_ARG, "conv3x3_eval_pair: bad dtype %d (bf16 / f32)", dtype);
+    const int es = dtype == BDN_F32 ? 4 : 2;
+    if (C0 <= 0 || (C0 * es) % 128) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_pair: C0=%d must be a multiple of %d", C0, 128 / es);
+    if (pool && (H < 2 || W < 2)) BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_pair: pooling needs H, W >= 2");
+    const size_t npix = (size_t)2 * B * H * W;
+    if (npix * (size_t)C0 * es >= ((size_t)1 << 32) || npix * (size_t)Cout * es >= ((size_t)1 << 32))
+        BDN_FAIL(BDN_E_SHAPE, "conv3x3_eval_pair: a tensor of N*H*W=%zu pixels reaches 4 GB; split the batch", npix);
+    ConvArgs a;
+    a.in0 = in; a.in1 = nullptr; a.C0 = C0; a.C1 = 0; a.ld0 = C0; a.ld1 = 0; a.in2 = nullptr; a.Dz = 0;
+    a.in_bn = nullptr; a.imgs_per_group = B; a.w = w; a.w_kgroups = 0; a.bias = nullptr; a.out = f_out; a.stats_partial = nullptr;
+    a.bs_z = nullptr; a.bs_bn = nullptr; a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
+    a.N = 2 * B; a.H = H; a.W = W; a.Cout = Cout;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mul = nullptr; a.ep_pool = pool; a.pair_stride = B;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
+    const ConvPlan g = conv_plan_pair(B, H, W, Cout);
+    a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == BDN_BF16 ? dispatch_conv_pair<bf16s>(a, g, st) : dispatch_conv_pair<float>(a, g, st);
 }
 
 extern "C" int bdn_conv3x3_eval_cls(int dtype, const void* in0, int C0, const void* w, const float* ep_scale, const float* ep_shift, void* act_out,
@@ -1006,7 +1126,7 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial; a.bs_z = nullptr; a.bs_bn = nullptr;
     a.N = N * D; a.H = H; a.W = W; a.Cout = Cout;
     a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
-    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
     a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
     const ConvPlan p = conv3d_plan(N * D, H, W, Cout);
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_ntiles = 0;

@@ -234,6 +234,9 @@ class BiDateEngine:
         # conv -> BatchNorm -> ReLU stage, date product / pooling / classifier in the epilogues); False = the training kernels on a
         # running-statistics table (the round 1-5 path, kept for A/B and as the checker of the new one in tests)
         self.eval_fused = True
+        # eval_pair: the second convolution of an encoder level runs on date-paired tiles (both dates of a pixel in one block: the skip product and
+        # both pooled maps leave from LDS, neither activation is stored); False = one launch per date (date 2 reads date 1's stored activation)
+        self.eval_pair = (1, 2, 3, 4, 5)       # encoder levels that take the paired form
         # The only tuning attributes (tools/archive/ab_flag.py A/Bs them in one process).  Everything round 1 and 2 measured and lost -- the
         # unfused BatchNorm-backward paths, relu(bn(z)) materialised for the weight gradient, the two-pass encoder skip backward,
         # release schedules of the weight-gradient GEMMs -- is gone from the product (DESIGN.md section 4 keeps the findings,
@@ -562,9 +565,9 @@ class BiDateEngine:
         """model.eval() forward on the packed input in ws.x0 (reference: train.py:125-172 validation, train.py:182-205 full-scene inference).
         Nothing depends on batch statistics, so every conv -> BatchNorm -> ReLU stage is ONE launch whose epilogue applies the folded
         running-statistics affine + ReLU and stores the ACTIVATION (bdn_conv3x3_eval): consumers stage plain bytes, there are no statistics
-        partials, no finalize / bn_eval launches.  The second convolution of an encoder level runs per date: date 1 stores its activation
-        and its pooled map, date 2 multiplies its own with date 1's in the copy-out (the skip relu(x_d2 * x_d1), models/bidate_model.py:35-38,
-        is what it stores -- its own activation never reaches HBM) and pools; product_pool / fuse_product launches are gone.  The last
+        partials, no finalize / bn_eval launches.  The second convolution of an encoder level runs on date-PAIRED tiles (both dates of the
+        same pixels in one block, bdn_conv3x3_eval_pair): the skip relu(x_d2 * x_d1) (models/bidate_model.py:35-38) and both pooled maps
+        leave from LDS and neither date's activation reaches HBM; product_pool / fuse_product launches are gone.  The last
         decoder convolution carries the 1x1 classifier (and, for scene inference, argmax + stitching) in its epilogue.
         Returns logits [B,n_classes,H,W] float32, or None when `mask` is given (uint8 [B,H,W], or the scene mask [Hs,Ws] with `origins`)."""
         B, H, W = ws.B, ws.H, ws.W
@@ -591,8 +594,13 @@ class BiDateEngine:
             za, zb = ws.z[La.name], ws.z[Lb.name]
             stage(La, src, La.cin, None, 0, za, 2 * B, hk, wk)
             pn = ws.pool[k + 1] if k < 5 else None
-            stage(Lb, za[:B], Lb.cin, None, 0, zb[:B], B, hk, wk, pool=pn[:B] if k < 5 else None)
-            stage(Lb, za[B:], Lb.cin, None, 0, ws.f[k], B, hk, wk, mul=zb[:B], pool=pn[B:] if k < 5 else None)
+            if k in self.eval_pair:
+                wf, _ = self._weights(Lb, P, False)
+                sc, sh = ev[Lb.name]
+                call('bdn_conv3x3_eval_pair', self.dt, ptr(za), Lb.cin, ptr(wf), ptr(sc), ptr(sh), ptr(ws.f[k]), ptr(pn), B, hk, wk, Lb.cout, st)
+            else:                                    # per date: date 1 stores its activation, date 2 multiplies its own with it in the copy-out
+                stage(Lb, za[:B], Lb.cin, None, 0, zb[:B], B, hk, wk, pool=pn[:B] if k < 5 else None)
+                stage(Lb, za[B:], Lb.cin, None, 0, ws.f[k], B, hk, wk, mul=zb[:B], pool=pn[B:] if k < 5 else None)
         # ---- decoder on the fused skips
         prev, cprev = ws.f[5], ENC_CH[4]
         logits = None

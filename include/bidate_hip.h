@@ -228,11 +228,16 @@ int bdn_bn_eval(const float* gamma, const float* beta, const float* running_mean
  *   epilogue: logits [N,ncls,H,W] f32 (NULL: not stored; bit-identical to bdn_outc_fwd on the stored activation), mask = argmax over
  *   classes (first maximum wins, train.py:199) as uint8 -- [N,H,W] when origins is NULL, else stitched into the scene mask [Hs,Ws] at
  *   origins[n] = (y0, x0) with bdn_argmax_stitch's ownership rule (utils/inference.py:187-236).  act_out (NULL: not stored) = the activation.
+ * bdn_conv3x3_eval_pair: the second convolution of an encoder level on BOTH dates of B patch pairs at once -- in [2B,H,W,C0] (date 1 first;
+ *   C0 a multiple of 64 bf16 / 32 f32 channels) -- on tiles that hold the two dates of the same pixels: f_out [B,H,W,Cout] = relu(x_d2 * x_d1)
+ *   (models/bidate_model.py:35-38), pool [2B,H/2,W/2,Cout] = nn.MaxPool2d(2) of both dates (NULL: none).  Neither date's activation is stored.
  * dtype BDN_BF16 or BDN_F32.  Every tensor below 4 GB. */
 int bdn_bn_eval_fold_multi(const void* desc, int n_layers, int max_C, float eps, void* stream);
 int bdn_conv3x3_eval(int dtype, const void* in0, int C0, const void* in1, int C1, const void* w,
                      const float* ep_scale, const float* ep_shift, void* out, const void* mul, void* pool,
                      int N, int H, int W, int Cout, void* stream);
+int bdn_conv3x3_eval_pair(int dtype, const void* in, int C0, const void* w, const float* ep_scale, const float* ep_shift,
+                          void* f_out, void* pool, int B, int H, int W, int Cout, void* stream);
 int bdn_conv3x3_eval_cls(int dtype, const void* in0, int C0, const void* w, const float* ep_scale, const float* ep_shift, void* act_out,
                          const float* cls_w, const float* cls_b, int ncls, float* logits, uint8_t* mask, const int32_t* origins,
                          int Hs, int Ws, int N, int H, int W, int Cout, void* stream);

@@ -107,6 +107,56 @@ def test_conv3x3_eval_stage(prec, case):
             assert torch.equal(from_nhwc(pool), O.maxpool2(from_nhwc(out)))
 
 
+PAIR_CASES = [
+    # B, H, W, C, Cout, pool
+    (2, 32, 32, 64, 64, True),        # encoder level 1: single-chunk 8x16x2 tiles
+    (3, 22, 45, 64, 64, True),        # ragged, odd sizes
+    (2, 16, 16, 128, 128, True),      # 8x8x2 tiles, 64-wide column tiles (small grid)
+    (40, 16, 16, 128, 128, True),     # 8x8x2 tiles, 128-wide column tiles, 1x4 waves
+    (3, 20, 11, 256, 256, True),      # ragged 8x8x2 tiles
+    (2, 8, 8, 512, 512, False),       # encoder level 5: 8x8 maps, product only
+    (70, 8, 8, 128, 128, False),      # 8x8 maps, 128-wide column tiles, 2x2 waves
+    (1, 5, 5, 64, 64, True),          # tiny odd map
+    (2, 24, 24, 128, 64, True),       # several chunks into 64 channels: 8x16x2 tiles, 4x1 waves
+]
+
+
+@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('case', PAIR_CASES)
+def test_conv3x3_eval_pair(prec, case):
+    """Date-paired stage against the oracle, and bit for bit against the per-date form (bdn_conv3x3_eval with mul / pool)."""
+    B, H, W, C, Cout, use_pool = case
+    dt, td = DT[prec]
+    x = rnd(prec, _rand((2 * B, C, H, W), 1))
+    w = _rand((Cout, C, 3, 3), 3, (2.0 / (9 * C)) ** 0.5)
+    sc, sh = _rand((Cout,), 5).abs() + 0.5, _rand((Cout,), 6, 0.3)
+    act = rnd(prec, torch.relu(O.conv3x3(x, rnd(prec, w), None) * sc[None, :, None, None] + sh[None, :, None, None]))
+    f_ref = rnd(prec, act[:B] * act[B:])
+    pool_ref = O.maxpool2(act) if use_pool else None
+    wf, _ = pack_w(prec, w, C)
+    dx, dsc, dsh = to_nhwc(prec, x), dev(sc), dev(sh)
+    f = torch.full((B, H, W, Cout), float('nan'), dtype=td, device='cuda')
+    pool = torch.full((2 * B, H // 2, W // 2, Cout), float('nan'), dtype=td, device='cuda') if use_pool else None
+    _lib.call('bdn_conv3x3_eval_pair', dt, dx.data_ptr(), C, wf.data_ptr(), dsc.data_ptr(), dsh.data_ptr(), f.data_ptr(),
+              pool.data_ptr() if use_pool else None, B, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert_close('skip product', from_nhwc(f), f_ref, TOL[prec], 1e-6)
+    if use_pool:
+        assert_close('pooled', from_nhwc(pool), pool_ref, TOL[prec], 1e-6)
+    # per-date form: date 1 stores its activation (+ pool), date 2 multiplies with it in the copy-out
+    a1 = torch.empty(B, H, W, Cout, dtype=td, device='cuda')
+    f2 = torch.empty_like(f)
+    pool2 = torch.empty_like(pool) if use_pool else None
+    _lib.call('bdn_conv3x3_eval', dt, dx[:B].data_ptr(), C, None, 0, wf.data_ptr(), dsc.data_ptr(), dsh.data_ptr(), a1.data_ptr(), None,
+              pool2[:B].data_ptr() if use_pool else None, B, H, W, Cout, st())
+    _lib.call('bdn_conv3x3_eval', dt, dx[B:].data_ptr(), C, None, 0, wf.data_ptr(), dsc.data_ptr(), dsh.data_ptr(), f2.data_ptr(), a1.data_ptr(),
+              pool2[B:].data_ptr() if use_pool else None, B, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert torch.equal(f2, f)                 # the same MFMA sequence per output pixel in both forms: the same bits
+    if use_pool:
+        assert torch.equal(pool2, pool)
+
+
 @pytest.mark.parametrize('prec', PRECS)
 @pytest.mark.parametrize('shape', [(3, 32, 32), (2, 20, 45), (5, 16, 16)])
 @pytest.mark.parametrize('ncls', [2, 1])
@@ -214,6 +264,12 @@ def test_eval_schedule_matches_the_training_kernel_eval_path(golden_dir, name, p
         old = model(x1, x2).cpu()
         eng.eval_fused = True
         cd, _ = eng.forward(x1, x2, {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}, training=False, class_map=True)
+        eng.eval_pair = ()
+        per_date = model(x1, x2).cpu()
+        eng.eval_pair = (1, 2, 3, 4, 5)
+    assert torch.equal(per_date, new)            # date-paired tiles and the per-date launches compute the same bits
+    with torch.no_grad():
+        pass
     scale = old.abs().max().item()
     d = (new - old).abs().max().item()
     print(f'\n[{name} {prec}] eval-shaped vs training-kernel eval path: max|dlogit|={d:.3e} of scale {scale:.1f}')
