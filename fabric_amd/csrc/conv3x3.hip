@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     const unsigned dmask = D3 ? ((dslice > 0 ? 1u : 0u) | 2u | (dslice + 1 < a.Dz ? 4u : 0u)) : 7u;
     static_assert(!D3 || TI == 1, "a 3x3x3 tile belongs to one depth slice");
 
-    // eval-mode single-chunk kernels (the full-resolution 64-channel layers: instruction-issue bound, 14.8 instructions per MFMA of which
-    // three quarters are prologue and epilogue): tiles whose halo lies inside the image take a prologue without bounds tests / zero fill
-    const bool interior = EV && ONE && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= a.H && x0 + TW + 1 <= a.W && n0 + (TI - 1) * istr < a.N;
+    // eval-mode kernels (above all the full-resolution 64-channel layers: instruction-issue bound, 14.8 instructions per MFMA of which
+    // three quarters are prologue and epilogue): tiles whose halo lies inside the image stage their patches without bounds tests / zero fill
+    const bool interior = EV && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= a.H && x0 + TW + 1 <= a.W && n0 + (TI - 1) * istr < a.N;
     // ---- activation patch: every thread owns NPU 16-byte units whose pixel / LDS offsets never change
     int p_pix[NPU];                                      // global pixel index of each unit (-1 = zero padding)
     {
@@ -216,8 +216,13 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
            are zeroed at the store */                                                                   \
         const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(src_ + cs_);                  \
         const unsigned cb_ = (unsigned)Cs_ * CF::ES;                                                    \
-        _Pragma("unroll") for (int i = 0; i < NPU; i++)                                                  \
-            preg[i] = *reinterpret_cast<const uint4*>(sb_ + ((unsigned)(p_pix[i] >= 0 ? p_pix[i] : p_fall) * cb_ + p_subb)); \
+        if (EV && interior) {                              /* block-uniform: every unit's pixel is inside the image */ \
+            _Pragma("unroll") for (int i = 0; i < NPU; i++)                                              \
+                preg[i] = *reinterpret_cast<const uint4*>(sb_ + ((unsigned)p_pix[i] * cb_ + p_subb));   \
+        } else {                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < NPU; i++)                                              \
+                preg[i] = *reinterpret_cast<const uint4*>(sb_ + ((unsigned)(p_pix[i] >= 0 ? p_pix[i] : p_fall) * cb_ + p_subb)); \
+        }                                                                                               \
         if constexpr (BB) {                                                                             \
             const unsigned char* zb_ = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(a.bb_z) + (c0_)); \
             const unsigned zc_ = (unsigned)a.C0 * CF::ES;                                               \
@@ -270,7 +275,9 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
             const int u_ = tid + i * 256;                  /* LDS offset recomputed: cheaper than 11 live registers */ \
             const int pix_ = u_ / UPP, xx_ = pix_ % TL::PW, t_ = pix_ / TL::PW;                          \
-            if (BRANCHFREE) {                              /* multi-chunk kernels: the staging is scheduled into the MFMAs */ \
+            if (BRANCHFREE && EV && interior) {            /* eval mode, halo inside the image: plain bytes, nothing to select */ \
+                *reinterpret_cast<uint4*>(pb_ + t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16) = preg[i];     \
+            } else if (BRANCHFREE) {                       /* multi-chunk kernels: the staging is scheduled into the MFMAs */ \
                 uint4 v_ = bn_ ? bnrelu_unit<T>(preg[i], sc_, sh_) : preg[i];                           \
                 const bool ok_ = p_pix[i] >= 0 && dvs_;                                                 \
                 v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
