@@ -20,6 +20,9 @@
 // coalesced NHWC stores.  Block ids are remapped so the N-tiles of one M-tile share an XCD's L2.
 #include "common.hpp"
 #include <type_traits>
+#ifndef BDN_X3_FUSED
+#define BDN_X3_FUSED 1      /* A/B switch of the round (tools/build_lib_variant.sh old "-DBDN_X3_FUSED=0") */
+#endif
 
 struct ConvArgs {
     const void* in0; const void* in1; int C0, C1;
@@ -85,7 +88,7 @@ template <> struct Mma<float> {
 
 // TO: element type of the OUTPUT tensor (and of bs_z).  TO = T except in the bf16x3 setting, whose operands are bf16 hi/lo
 // splits of float32 tensors and whose outputs are float32.
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool BF = true, typename TO = T>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool BF = true, typename TO = T, int X3 = 0>
 struct ConvCfg {
     using TL = Tile<TH, TW, TI>;
     static constexpr int ES = sizeof(T);
@@ -110,10 +113,11 @@ struct ConvCfg {
     static constexpr int PATCH_BYTES = PATCH_ROWS * ROWP;
     // double-buffer when two blocks still fit a CU; the single-chunk kernels (BF == false) never fill a second buffer, and without
     // it their 8x16 instantiation fits three blocks per CU instead of two
-    static constexpr int PBUF = (BF && 2 * PATCH_BYTES <= 64 * 1024) ? 2 : 1;
+    // X3 (bf16x3 with the split product fused into one reduction): TWO patches per chunk -- the hi and the lo part of the operand -- single-buffered
+    static constexpr int PBUF = X3 ? 1 : ((BF && 2 * PATCH_BYTES <= 64 * 1024) ? 2 : 1);
     static constexpr int OSTR = BN * OES + 16;
     static constexpr int NPU = (TL::NPIX * UPP + 255) / 256;
-    static constexpr int MAIN_BYTES = PBUF * PATCH_BYTES;
+    static constexpr int MAIN_BYTES = (X3 ? 2 : PBUF) * PATCH_BYTES;
     static constexpr int EPI_BYTES = BM * OSTR + 4 * BN * 2 * 4;
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(WM * WN == 4, "4 waves");
@@ -128,13 +132,13 @@ struct ConvCfg {
 // ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false, int X3 = 0>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 // the multi-chunk 64-wide instantiation on 8 x 16 tiles needs 171 registers: at three blocks per CU (168) it spilled three of them;
 // two blocks per CU measure the same (d1a fwd 74.6 -> 73.8 us, step 6.16 ms either way) without scratch
 __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN == 64) || (BN == 64 && TH == 8))) ? ((!ONE && BN == 64 && TH == 8) ? 2 : 3) : 2) void conv3x3_kernel(ConvArgs a) {
-    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
+    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO, X3>;
     using TL = typename CF::TL;
     constexpr int MI = CF::MI, NJ = CF::NJ, KG = CF::KG, PSTR = CF::PSTR, ROWP = CF::ROWP;
     constexpr int EPU = CF::EPU, UPP = CF::UPP, NPU = CF::NPU, CK = CF::CK, PBUF = CF::PBUF;
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     constexpr bool BRANCHFREE = !ONE;
     static_assert(!BB || (sizeof(T) == 2 && sizeof(TO) == 2 && !D3 && TI == 1), "BatchNorm backward on load: bf16 2-D launches, one image per tile");
     static_assert(!EV || (!BB && !D3 && sizeof(T) == sizeof(TO)), "eval-mode epilogue: plain 2-D launches");
+    static_assert(X3 == 0 || ((X3 == 2 || X3 == 3) && sizeof(T) == 2 && sizeof(TO) == 4 && CKB == 128 && !ONE && !D3 && !BB && !EV), "fused split product: bf16 operands, float32 outputs");
     uint4 preg[NPU];
     uint4 pregz[BB ? NPU : 1];                           // BB: the z units of the same pixels
 #define LOAD_PATCH(c0_)                                                                                  \
@@ -292,7 +297,34 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
 
     // the first patch is requested before anything else is computed: the rest of the prologue (LDS offsets, accumulator
     // clear, filter addressing) runs in the shadow of its HBM latency
-    if (EV && ONE && interior) {
+    // X3: the operand is the [hi | lo] split of a float32 tensor (bdn_split_pack: [pixel][2 C0], hi at channel c, lo at C0 + c); a chunk
+    // stages BOTH parts of its 64 channels, into two patches
+    uint4 pregl[X3 ? NPU : 1];
+#define X3_LOAD(c0_)                                                                                     \
+    {                                                                                                   \
+        const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(a.in0) + (c0_)); \
+        const unsigned cb_ = (unsigned)a.ld0 * CF::ES, lo_ = (unsigned)a.C0 * CF::ES;                   \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
+            const unsigned o_ = (unsigned)(p_pix[i] >= 0 ? p_pix[i] : 0) * cb_ + p_subb;                \
+            preg[i] = *reinterpret_cast<const uint4*>(sb_ + o_);                                        \
+            pregl[i] = *reinterpret_cast<const uint4*>(sb_ + o_ + lo_);                                 \
+        }                                                                                               \
+    }
+#define X3_STORE()                                                                                       \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
+            const int u_ = tid + i * 256, pix_ = u_ / UPP, xx_ = pix_ % TL::PW, t_ = pix_ / TL::PW;      \
+            const bool ok_ = p_pix[i] >= 0;                                                             \
+            uint4 h_ = preg[i], l_ = pregl[i];                                                          \
+            h_.x = ok_ ? h_.x : 0u; h_.y = ok_ ? h_.y : 0u; h_.z = ok_ ? h_.z : 0u; h_.w = ok_ ? h_.w : 0u; \
+            l_.x = ok_ ? l_.x : 0u; l_.y = ok_ ? l_.y : 0u; l_.z = ok_ ? l_.z : 0u; l_.w = ok_ ? l_.w : 0u; \
+            const int lo_ = t_ * ROWP + xx_ * PSTR + (u_ % UPP) * 16;                                   \
+            *reinterpret_cast<uint4*>(smem + lo_) = h_;                                                 \
+            *reinterpret_cast<uint4*>(smem + CF::PATCH_BYTES + lo_) = l_;                               \
+        }                                                                                               \
+    }
+    if constexpr (X3 != 0) X3_LOAD(0)
+    else if (EV && ONE && interior) {
         const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(a.in0);
         const unsigned cb_ = (unsigned)a.ld0 * CF::ES;
 #pragma unroll
@@ -389,6 +421,61 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     }
 #define STEP3(s_) STEP((s_), r0, r2) STEP((s_) + 1, r1, r0) STEP((s_) + 2, r2, r1)
 
+    if constexpr (X3 != 0) {
+        // ---- bf16x3 with the split product fused into ONE reduction (round 6).  The operand's hi and lo parts of a chunk sit in two LDS
+        // patches; a k-step (tap, k-group) loads the w_hi fragment (and for three terms the w_lo fragment) ONCE and issues
+        //     acc += a_hi w_hi;  acc += a_lo w_hi;  [acc += a_hi w_lo]
+        // per pixel fragment: 2 (3) MFMAs per LDS fragment read and 2 MI (3 MI) MFMAs per filter fragment streamed through the L1, where the
+        // K = [hi | lo | hi] walk of rounds 3-5 had 1 and MI -- the vector-memory fragment is the expensive feed instruction
+        // (profiles/r5_feed_power.txt) -- and the hi patch is staged once instead of twice.  Filter image: bdn_pack_weights(BDN_BF16X3)
+        // rows [w_hi | w_hi | w_lo] of 3 C0 channels per tap: w_hi from the first third, w_lo from the last.
+        constexpr int NSTEP = 9 * KG;
+        static_assert(NSTEP % 3 == 0, "ring of three filter sets");
+        const unsigned lo_rec = 2u * (unsigned)(a.C0 / KCH);             // record offset of w_lo inside a (cout block, tap) row
+        int chunk = 0;
+        for (int c0 = 0; c0 < a.C0; c0 += CK, chunk++) {
+            const bool more = c0 + CK < a.C0;
+            X3_STORE()
+            __syncthreads();
+            if (more) X3_LOAD(c0 + CK)                                   // in flight under this chunk's MFMAs
+            const unsigned rec0 = (unsigned)chunk * KG;
+            uint4 bh[3][NJ], bl[X3 == 3 ? 3 : 1][NJ], ah[2][MI], al[2][MI];
+#define X3_LDB(set_, st_)                                                                                \
+            {                                                                                           \
+                const size_t o_ = ((size_t)((st_) / KG) * kgroups + rec0 + ((st_) % KG)) * 1024;        \
+                bh[set_][0] = LDB(wb0 + o_, 0); if (NJ > 1) bh[set_][NJ - 1] = LDB(wb1 + o_, 0);        \
+                if (X3 == 3) { bl[(X3 == 3) ? (set_) : 0][0] = LDB(wb0 + o_, lo_rec); if (NJ > 1) bl[(X3 == 3) ? (set_) : 0][NJ - 1] = LDB(wb1 + o_, lo_rec); } \
+            }
+#define X3_LDA(set_, st_)                                                                                \
+            {                                                                                           \
+                const int ao_ = (((st_) / KG) / 3) * ROWP + (((st_) / KG) % 3) * PSTR + ((st_) % KG) * 32; \
+                _Pragma("unroll") for (int mi = 0; mi < MI; mi++) {                                      \
+                    ah[set_][mi] = *reinterpret_cast<const uint4*>(smem + a_off[mi] + ao_);             \
+                    al[set_][mi] = *reinterpret_cast<const uint4*>(smem + CF::PATCH_BYTES + a_off[mi] + ao_); \
+                }                                                                                       \
+            }
+            X3_LDB(0, 0)
+            X3_LDB(1, 1)
+            X3_LDA(0, 0)
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; s_++) {
+                if (s_ + 2 < NSTEP) X3_LDB((s_ + 2) % 3, s_ + 2)
+                if (s_ + 1 < NSTEP) X3_LDA((s_ + 1) & 1, s_ + 1)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; nj++) {
+                        Mma<T>::run(ah[s_ & 1][mi], bh[s_ % 3][nj], acc[mi][nj]);
+                        Mma<T>::run(al[s_ & 1][mi], bh[s_ % 3][nj], acc[mi][nj]);
+                        if (X3 == 3) Mma<T>::run(ah[s_ & 1][mi], bl[(X3 == 3) ? (s_ % 3) : 0][nj], acc[mi][nj]);
+                    }
+            }
+#undef X3_LDB
+#undef X3_LDA
+            __syncthreads();                                             // everyone done reading before the next chunk's patches land
+        }
+    } else {
     // prologue: first patch -> LDS buffer 0, steps 0 and 1 -> ring slots 0 and 1
     LOAD_R(r0, 0, 0)
     LOAD_R(r1, 1, 0)
@@ -417,6 +504,9 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         }
         __syncthreads();
     }
+    }
+#undef X3_LOAD
+#undef X3_STORE
 #undef LDB
 #undef LOAD_R
 #undef STEP
@@ -768,17 +858,17 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
 static thread_local bool g_conv_query = false;
 static thread_local char g_conv_variant[160];
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false, int X3 = 0>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
-    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO>;
+    using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO, X3>;
     if (g_conv_query) {
         // the full template spelling, so that a profiler can match rocprofv3's kernel names exactly ("bf16" = unsigned short)
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s,%s>",
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s,%s,%d>",
                  sizeof(T) == 2 ? "bf16" : "float", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false",
-                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false", EV ? "true" : "false");
+                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false", EV ? "true" : "false", X3);
         return BDN_OK;
     }
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB, EV>;
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB, EV, X3>;
     BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
@@ -848,6 +938,34 @@ static int dispatch_conv_x3(const ConvArgs& a, const ConvPlan& p, hipStream_t st
     return launch_conv<bf16s, CKB, 8, 8, 2, 64, 2, 2, false, float>(a, g.n_mtiles, st);
 }
 
+// bf16x3 with the split product fused into one reduction (operands of at least 64 channels): two patches per chunk in LDS, so no 16x16 tiles
+static ConvPlan conv_plan_x3f(int N, int H, int W, int Cout, int imgs_per_group) {
+    ConvPlan p;
+    TileGeom& g = p.g;
+    if (W <= 8 && H <= 8 && imgs_per_group % 2 == 0) { g.TI = 2; g.TH = 8; g.TW = 8; }
+    else { g.TI = 1; g.TH = 8; g.TW = 16; }
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    g.n_mtiles = ((N + g.TI - 1) / g.TI) * g.tiles_y * g.tiles_x;
+    p.BN = (g.TI == 1 && Cout % 128 == 0 && (long)g.n_mtiles * (Cout / 128) >= 512) ? 128 : 64;
+    return p;
+}
+
+template <int X3>
+static int dispatch_conv_x3f(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+    const TileGeom& g = p.g;
+    if (g.TI == 1 && p.BN == 128) return launch_conv<bf16s, 128, 8, 16, 1, 128, 1, 4, false, float, false, false, false, X3>(a, g.n_mtiles, st);
+    if (g.TI == 1) return launch_conv<bf16s, 128, 8, 16, 1, 64, 2, 2, false, float, false, false, false, X3>(a, g.n_mtiles, st);
+    return launch_conv<bf16s, 128, 8, 8, 2, 64, 2, 2, false, float, false, false, false, X3>(a, g.n_mtiles, st);
+}
+
+// tiles of a launch by operand type: the bf16x3 kernels with the fused split product (C0 a multiple of 64) have their own tile plan
+extern "C" int bdn_conv3x3_num_mtiles_ex(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || imgs_per_group <= 0) return 0;
+    if (BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) && C0 % 64 == 0) return conv_plan_x3f(N, H, W, Cout, imgs_per_group).g.n_mtiles;
+    return conv_plan(N, H, W, Cout, imgs_per_group).g.n_mtiles;
+}
+
 extern "C" int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || imgs_per_group <= 0) return 0;
     return conv_plan(N, H, W, Cout, imgs_per_group).g.n_mtiles;
@@ -877,7 +995,8 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
         // BDN_BF16X2: K = [hi | lo] against the first two thirds of every image row -- a_hi*w_hi + a_lo*w_hi
         if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3x3(bf16x3): one split-packed, plain operand (bdn_split_pack does cat / BatchNorm+ReLU)");
         if (C0 % 16) BDN_FAIL(BDN_E_SHAPE, "conv3x3(bf16x3): C0=%d must be a multiple of 16", C0);
-        if (dtype == BDN_BF16X3) { a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0; }
+        if (BDN_X3_FUSED && C0 % 64 == 0) { a.in1 = nullptr; a.C0 = C0; a.C1 = 0; a.ld0 = 2 * C0; a.ld1 = 0; a.w_kgroups = 3 * C0 / 16; }     // fused split product (below)
+        else if (dtype == BDN_BF16X3) { a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0; }
         else { a.in1 = nullptr; a.C0 = 2 * C0; a.C1 = 0; a.ld0 = 2 * C0; a.ld1 = 0; a.w_kgroups = 3 * C0 / 16; }
     }
     {   // the kernels address every tensor as one uniform base + a 32-bit byte offset
@@ -893,9 +1012,11 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
     a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
-    const ConvPlan g = conv_plan(N, H, W, Cout, imgs_per_group);
+    const bool x3f = BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) && C0 % 64 == 0;
+    const ConvPlan g = x3f ? conv_plan_x3f(N, H, W, Cout, imgs_per_group) : conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (x3f) return dtype == BDN_BF16X3 ? dispatch_conv_x3f<3>(a, g, st) : dispatch_conv_x3f<2>(a, g, st);
     if (bb_z) {
         if (dtype != BDN_BF16 || C0 != 64 || in1 || in_mode != BDN_IN_PLAIN)
             BDN_FAIL(BDN_E_SHAPE, "conv3x3_dgrad_bb: bf16, one plain source of C0 = 64 channels (got %d)", C0);

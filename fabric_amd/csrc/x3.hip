@@ -117,8 +117,97 @@ __global__ void pack_weights_x3_multi_kernel(const PackDesc* __restrict__ desc) 
     }
 }
 
+// Regular layers (Cin a multiple of 64 and unpadded, Cout of 32: 17 of BiDateNet's 18) go through LDS, as pack_weights_tiles_kernel (head.hip)
+// does for the bf16 setting: a block takes 32 output channels x 64 input channels x 9 taps, reads them as 32 contiguous 2304-byte rows of the
+// OIHW master (16-byte loads) and writes complete 1 KB fragment records of both images with 16-byte stores -- the hi part twice (thirds 0 and 1
+// of a row), then, in a second pass over the same rows (L2 hits), the lo part (third 2).  The element-wise kernel above gathers 4-byte values
+// 36 bytes apart and stores 2 bytes per lane six times: 229 us for the 190 MB of a step, alone at the start of every bf16x3 step (round 6).
+__device__ __forceinline__ bool pack_regular_x3(const PackDesc& d) { return d.Cin == d.Cinp && d.Cin % 64 == 0 && d.Cout % 32 == 0; }
+__global__ __launch_bounds__(256) void pack_weights_x3_tiles_kernel(const PackDesc* __restrict__ desc, int n_layers) {
+    constexpr int ROW = 9 * 64 + 8;                            // LDS elements per output channel: [tap][ci] + 16 bytes of padding
+    __shared__ __attribute__((aligned(16))) bf16s t[32 * ROW];
+    const int tid = threadIdx.x;
+    for (int item = blockIdx.x;; item += gridDim.x) {
+        int l = 0, local = item;
+        for (; l < n_layers; l++) {
+            const int cnt = pack_regular_x3(desc[l]) ? (desc[l].Cout / 32) * (desc[l].Cin / 64) : 0;
+            if (local < cnt) break;
+            local -= cnt;
+        }
+        if (l == n_layers) return;                             // uniform for the block
+        const PackDesc d = desc[l];
+        const int ncc = d.Cin / 64, cb = local / ncc, cc = local % ncc, co0 = cb * 32, ci0 = cc * 64;
+        bf16s* wf = reinterpret_cast<bf16s*>(d.wf); bf16s* wd = reinterpret_cast<bf16s*>(d.wd);
+#pragma unroll 1
+        for (int part = 0; part < 2; part++) {                 // 0: hi (stored to thirds 0 and 1), 1: lo (third 2)
+            __syncthreads();                                   // the previous pass's LDS reads are done
+            for (int q = tid; q < 32 * 144; q += 256) {        // 144 float4 per output-channel row
+                const int r = q / 144, o4 = (q % 144) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(d.w + ((size_t)(co0 + r) * d.Cin + ci0) * 9 + o4);
+                const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int o = o4 + e, ci = o / 9, tap = o % 9;
+                    const bf16s hi = (bf16s)f2bf(f[e]);
+                    t[r * ROW + tap * 64 + ci] = part == 0 ? hi : (bf16s)f2bf(f[e] - bf2f(hi));
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < 36 * 64; u += 256) {         // 36 records x 64 lanes, 16 bytes each
+                const int rec_l = u >> 6, lane = u & 63;
+                if (wf) {      // record (tap, kq): lane = co & 31 + 32 * (ci % 16) / 8, 8 consecutive ci
+                    const int tap = rec_l >> 2, kq = rec_l & 3;
+                    const size_t row = ((size_t)cb * 9 + tap) * (3 * d.Cin / 16), k = ci0 / 16 + kq;
+                    const uint4 v = *reinterpret_cast<const uint4*>(t + (lane & 31) * ROW + tap * 64 + kq * 16 + (lane >> 5) * 8);
+                    if (part == 0) {
+                        *reinterpret_cast<uint4*>(wf + (row + k) * 512 + lane * 8) = v;
+                        *reinterpret_cast<uint4*>(wf + (row + d.Cin / 16 + k) * 512 + lane * 8) = v;
+                    } else *reinterpret_cast<uint4*>(wf + (row + 2 * (d.Cin / 16) + k) * 512 + lane * 8) = v;
+                }
+                if (wd) {      // roles swapped, taps rotated: record (ci block, 8 - tap, co group of 16): 8 consecutive co
+                    const int cbi = rec_l / 18, rem = rec_l % 18, tap = rem >> 1, kg = rem & 1;
+                    const int ci = cbi * 32 + (lane & 31), co8 = kg * 16 + (lane >> 5) * 8;
+                    unsigned short h[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) h[e] = t[(co8 + e) * ROW + tap * 64 + ci];
+                    const uint4 v = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+                    const size_t row = ((size_t)(ci0 / 32 + cbi) * 9 + (8 - tap)) * (3 * d.Cout / 16), k = co0 / 16 + kg;
+                    if (part == 0) {
+                        *reinterpret_cast<uint4*>(wd + (row + k) * 512 + lane * 8) = v;
+                        *reinterpret_cast<uint4*>(wd + (row + d.Cout / 16 + k) * 512 + lane * 8) = v;
+                    } else *reinterpret_cast<uint4*>(wd + (row + 2 * (d.Cout / 16) + k) * 512 + lane * 8) = v;
+                }
+            }
+        }
+    }
+}
+// the element-wise kernel restricted to the layers the tile kernel does not take (the 13-band first layer)
+__global__ void pack_weights_x3_irregular_kernel(const PackDesc* __restrict__ desc) {
+    if (pack_regular_x3(desc[blockIdx.y])) return;
+    const PackDesc d = desc[blockIdx.y];
+    const size_t total = (size_t)d.Cout * 9 * d.Cinp;
+    bf16s* wf = reinterpret_cast<bf16s*>(d.wf); bf16s* wd = reinterpret_cast<bf16s*>(d.wd);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = i % d.Cinp; const size_t t = i / d.Cinp; const int tap = t % 9; const int co = t / 9;
+        const float v = ci < d.Cin ? d.w[((size_t)co * d.Cin + ci) * 9 + tap] : 0.f;
+        const bf16s hi = (bf16s)f2bf(v);
+        const bf16s lo = (bf16s)f2bf(v - bf2f(hi));
+        if (wf) {
+            wf[wfrag_index<bf16s>(co, tap, ci, 3 * d.Cinp)] = hi;
+            wf[wfrag_index<bf16s>(co, tap, d.Cinp + ci, 3 * d.Cinp)] = hi;
+            wf[wfrag_index<bf16s>(co, tap, 2 * d.Cinp + ci, 3 * d.Cinp)] = lo;
+        }
+        if (wd) {
+            wd[wfrag_index<bf16s>(ci, 8 - tap, co, 3 * d.Cout)] = hi;
+            wd[wfrag_index<bf16s>(ci, 8 - tap, d.Cout + co, 3 * d.Cout)] = hi;
+            wd[wfrag_index<bf16s>(ci, 8 - tap, 2 * d.Cout + co, 3 * d.Cout)] = lo;
+        }
+    }
+}
+
 int bdn_pack_weights_x3_multi(const PackDesc* desc, int n_layers, hipStream_t st) {
-    hipLaunchKernelGGL(pack_weights_x3_multi_kernel, dim3(512, n_layers), dim3(256), 0, st, desc);
+    hipLaunchKernelGGL(pack_weights_x3_tiles_kernel, dim3(1024), dim3(256), 0, st, desc, n_layers);
+    hipLaunchKernelGGL(pack_weights_x3_irregular_kernel, dim3(32, n_layers), dim3(256), 0, st, desc);
     BDN_CHECK_LAUNCH("pack_weights_x3_multi");
     return BDN_OK;
 }

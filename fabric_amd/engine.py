@@ -136,7 +136,9 @@ class Workspace:
         for L in eng.layers:
             hk, wk = self.dims[L.level - 1]
             n, ipg = (2 * B, B) if L.enc else (B, B)
-            n_stats = max(n_stats, lib.bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg) * 2 * L.cout)
+            n_stats = max(n_stats, eng.mtiles(n, hk, wk, L.cin, L.cout, ipg) * 2 * L.cout)
+            if L.name != 'e1a':                        # data-gradient launches with fused BatchNorm-backward sums: rows of THEIR tile plan
+                n_stats = max(n_stats, eng.mtiles(n, hk, wk, L.cout, L.cin, ipg) * 2 * L.cin)
             if L.name == 'd4b':
                 n_stats = max(n_stats, lib.bdn_outc_bwd_rows(eng.dt, B, hk, wk, L.cout) * 2 * L.cout)
             if not L.enc and L.name[2] == 'b' and L.level > 1:      # upsample2x_bwd_bs leaves this layer's BatchNorm-backward partials here
@@ -294,6 +296,11 @@ class BiDateEngine:
                           2.0 * n * h * w * cout * 9 * (c0 + c1), e0, e1))
 
     # ------------------------------------------------------------------ helpers
+    def mtiles(self, n, h, w, c0, cout, ipg):
+        """Spatial tiles (= rows of per-tile partial sums) of a convolution launch with c0 operand channels in this numerics setting: the
+        bf16x3 kernels with the fused split product have their own tile plan (no 16 x 16 tiles)."""
+        return _lib.load().bdn_conv3x3_num_mtiles_ex(self.mdt, n, h, w, c0, cout, ipg)
+
     def _side_stream(self, device):
         """The process-wide weight-gradient stream of the device (fabric_amd/streams.py)."""
         from . import streams
@@ -400,7 +407,7 @@ class BiDateEngine:
                          n, hk, wk, L.cout, st)
         G = n // ipg
         if training:
-            nt = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cout, ipg)
+            nt = self.mtiles(n, hk, wk, c0 + c1, L.cout, ipg)
             if before_finalize is not None:
                 before_finalize()
             call('bdn_bn_finalize', ptr(stats), nt, G, L.cout, ipg * hk * wk,
@@ -757,7 +764,7 @@ class BiDateEngine:
                              ptr(ws.z[prev.name]) if has else None, ptr(ws.bn[prev.name]) if has else None, ptr(ws.stats) if has else None,
                              ptr(dz), n, hk, wk, L.cin, st, fn='bdn_conv3x3_dgrad_bb', bb=True)
             if has:
-                return dz, out, _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // G
+                return dz, out, self.mtiles(n, hk, wk, L.cout, L.cin, ipg) // G
             return dz, out
 
         def wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, stp):
@@ -865,7 +872,7 @@ class BiDateEngine:
             self._timed_conv(n, hk, wk, L.cout, 0, L.cin, ipg,
                              ddt, ptr(dz), L.cout, ptr(wd), ptr(out), ptr(ws.z[prev.name]), ptr(ws.bn[prev.name]),
                              ipg, ptr(ws.stats), n, hk, wk, L.cin, st, fn='bdn_conv3x3_dgrad_bs')
-            rows = _lib.load().bdn_conv3x3_num_mtiles(n, hk, wk, L.cin, ipg) // (n // ipg)
+            rows = self.mtiles(n, hk, wk, L.cout, L.cin, ipg) // (n // ipg)
             return out, rows
 
         # ---- classifier: its data gradient is never stored -- bdn_outc_bwd leaves the BatchNorm-backward partial sums of d4b, and

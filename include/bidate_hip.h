@@ -88,6 +88,9 @@ int bdn_conv3x3(int dtype, const void* in0, int C0, const void* in1, int C1,
                 const void* w, const float* bias, void* out, float* stats_partial,
                 int N, int H, int W, int Cout, void* stream);
 int bdn_conv3x3_num_mtiles(int N, int H, int W, int Cout, int imgs_per_group);
+/* The same by operand type: BDN_BF16X3 / BDN_BF16X2 launches with C0 (logical operand channels) a multiple of 64 run the kernels that fuse the
+ * split product into one reduction (two LDS patches per chunk), which have their own tile plan; every other case equals bdn_conv3x3_num_mtiles. */
+int bdn_conv3x3_num_mtiles_ex(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group);
 /* Name of the kernel instantiation bdn_conv3x3 runs for a shape, e.g. "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false>"
  * (the rocprofv3 name with `unsigned short` spelled bf16); "" for an unsupported shape.  Thread-local buffer. */
 const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group);

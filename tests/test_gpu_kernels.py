@@ -688,6 +688,32 @@ def test_pack_weights_multi_equals_per_layer_pack(prec):
             assert torch.equal(wd, rd), (co, ci)
 
 
+def test_pack_weights_multi_bf16x3_equals_per_layer_pack():
+    """BDN_BF16X3: the LDS-tiled packer of the regular layers (round 6) and the element-wise one of the rest write the same
+    [w_hi | w_hi | w_lo] images as bdn_pack_weights(BDN_BF16X3) layer by layer."""
+    import struct
+    X3 = _lib.BDN_BF16X3
+    layers = [(64, 13, 16, False), (64, 64, 64, True), (128, 64, 64, True), (256, 384, 384, True), (64, 128, 128, True), (32, 64, 64, False)]
+    ws, outs, rec = [], [], b''
+    for i, (co, ci, cip, has_wd) in enumerate(layers):
+        w = dev(_rand((co, ci, 3, 3), 450 + i))
+        wf = torch.full((co * 9 * 3 * cip,), 7.0, dtype=torch.bfloat16, device='cuda')
+        wd = torch.full((co * 9 * 3 * cip,), 7.0, dtype=torch.bfloat16, device='cuda') if has_wd else None
+        ws.append((w, co, ci, cip)); outs.append((wf, wd))
+        rec += struct.pack('<QQQiiii', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if has_wd else 0, co, ci, cip, 0)
+    desc = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+    _lib.call('bdn_pack_weights_multi', X3, desc.data_ptr(), len(ws), st())
+    torch.cuda.synchronize()
+    for (w, co, ci, cip), (wf, wd) in zip(ws, outs):
+        rf = torch.empty_like(wf)
+        rd = torch.empty_like(wd) if wd is not None else None
+        _lib.call('bdn_pack_weights', X3, w.data_ptr(), rf.data_ptr(), rd.data_ptr() if rd is not None else None, co, ci, cip, st())
+        torch.cuda.synchronize()
+        assert torch.equal(wf, rf), (co, ci)
+        if wd is not None:
+            assert torch.equal(wd, rd), (co, ci)
+
+
 @pytest.mark.parametrize('case', [(4, 32, 32, 2, 64), (6, 37, 50, 3, 64), (2, 128, 128, 1, 64), (4, 24, 16, 2, 80)])
 def test_first_layer_wgrad_with_fused_bn_bwd(case):
     """bdn_bn_bwd_finalize + bdn_conv3x3_wgrad_bnbwd == bdn_bn_bwd_apply + bdn_conv3x3_wgrad (bf16, 13 real channels padded to
@@ -926,7 +952,7 @@ def test_split_pack_is_the_exact_hi_lo_split(case):
 
 
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 1), (2, 8, 8, 128, 64, 2), (1, 22, 45, 16, 64, 1), (3, 19, 33, 64, 128, 3),
-                                  (2, 12, 12, 192, 64, 2)])
+                                  (2, 12, 12, 192, 64, 2), (36, 32, 32, 128, 256, 18), (2, 8, 8, 256, 128, 1)])
 def test_conv3x3_bf16x3_forward_dgrad_wgrad(case):
     """The bf16 kernels on split operands (three times the reduction length) against the float32 oracle: forward with
     statistics, data gradient and weight gradient all within 1e-4 of the tensor's magnitude (a plain bf16 GEMM sits at 1e-2)."""
@@ -946,7 +972,7 @@ def test_conv3x3_bf16x3_forward_dgrad_wgrad(case):
     wdev = dev(w)
     _lib.call('bdn_pack_weights', X3, wdev.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else None, Cout, Cin, Cin, st())
     out = torch.full((N, H, W, Cout), float('nan'), device='cuda')
-    nt = lib.bdn_conv3x3_num_mtiles(N, H, W, Cout, ipg)
+    nt = lib.bdn_conv3x3_num_mtiles_ex(X3, N, H, W, Cin, Cout, ipg)         # (operands of >= 64 channels: the fused-split-product kernels' own tile plan)
     stats = torch.full((nt, 2, Cout), float('nan'), device='cuda')
     bd = dev(b)
     _lib.call('bdn_conv3x3', X3, sp.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg, wf.data_ptr(), bd.data_ptr(), out.data_ptr(),

@@ -36,6 +36,9 @@ def test_argument_validation_needs_no_gpu():
     assert lib.bdn_conv3x3_num_mtiles(128, 128, 128, 64, 64) == 128 * 8 * 8      # 16x16 tiles for 64-wide outputs
     assert lib.bdn_conv3x3_num_mtiles(128, 128, 128, 128, 64) == 128 * 16 * 8    # 8x16 tiles
     assert lib.bdn_conv3x3_num_mtiles(128, 8, 8, 512, 64) == 64                   # two 8x8 images per tile
+    assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16X3, 128, 128, 128, 64, 64, 64) == 128 * 16 * 8     # fused split product: no 16x16 tiles
+    assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16X3, 128, 128, 128, 16, 64, 64) == 128 * 8 * 8      # 16-channel operand: the K = [hi | lo | hi] kernels
+    assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16, 128, 128, 128, 64, 64, 64) == 128 * 8 * 8
     assert lib.bdn_wgrad_workspace_bytes(2, 16, 16, 64, 64, 1) > 0
     with pytest.raises(RuntimeError, match='null pointer'):
         _lib.call('bdn_conv3x3', 1, None, 64, None, 0, 0, None, 1, None, None, None, None, 1, 8, 8, 64, None)
@@ -58,8 +61,8 @@ def test_argument_validation_needs_no_gpu():
     assert wsb(BDN_BF16X3, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0) > half             # doubled operands + the quadrant tile
     assert lib.bdn_wgrad_workspace_bytes(128, 64, 64, 128, 128, 64) >= wsb(BDN_BF16X3, 128, 64, 64, 128, 128, 0, 64, IN_PLAIN, 0)
     assert lib.bdn_conv3d_num_mtiles(8, 5, 128, 128) == 8 * 5 * 16 * 8
-    assert lib.bdn_conv3x3_variant(BDN_BF16, 128, 64, 64, 128, 0, 128, 64) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false,false>'
-    assert lib.bdn_conv3x3_variant(BDN_BF16X3, 128, 64, 64, 128, 0, 128, 64).endswith(b'float,false,false,false>')
+    assert lib.bdn_conv3x3_variant(BDN_BF16, 128, 64, 64, 128, 0, 128, 64) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false,false,0>'
+    assert lib.bdn_conv3x3_variant(BDN_BF16X3, 128, 64, 64, 128, 0, 128, 64).endswith(b'float,false,false,false,3>')
     for name, args, msg in (
             ('bdn_conv3d', (BDN_BF16, None, 64, 0, None, 1, None, None, None, None, 1, 1, 8, 8, 64, None), 'null pointer'),
             ('bdn_conv3d', (7, 1, 64, 0, None, 1, 1, None, 1, None, 1, 1, 8, 8, 64, None), 'bad dtype'),
