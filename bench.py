@@ -410,20 +410,24 @@ def parity_leg(dev, B, C, S):
             ts = TrainStep(m, lr=1e-3)
             ms = _time_steps(ts, x1, x2, lbl, warm, n) * 1e3
             out[prec] = {'pairs_per_s': B / ms * 1e3, 'ms_per_step': ms}
-            if prec == 'bf16x3':                                   # the same setting with every backward GEMM on three terms too
-                m.engine().x3_bwd_terms = 3
-                ms3 = _time_steps(ts, x1, x2, lbl, 3, n) * 1e3
-                out[prec]['three_term_backward'] = {'pairs_per_s': B / ms3 * 1e3, 'ms_per_step': ms3}
+            if prec == 'bf16x3':                                   # the same forward with two-term backward GEMMs: precision='bf16x3-fast'
+                m.engine().x3_bwd_terms = 2
+                ms2 = _time_steps(ts, x1, x2, lbl, 3, n) * 1e3
+                out['bf16x3_fast'] = {'pairs_per_s': B / ms2 * 1e3, 'ms_per_step': ms2}
+                out[prec]['three_term_backward'] = dict(out[prec])   # (the same numbers under the key round 5's line used)
             del ts
         del m
         torch.cuda.empty_cache()
     for prec in ('bf16x3', 'bf16'):
         out.setdefault(prec, {})['max_abs_dlogit_vs_fp32_setting'] = float((logits[prec] - logits['fp32']).abs().max())
+    out['bf16x3_fast']['max_abs_dlogit_vs_fp32_setting'] = out['bf16x3']['max_abs_dlogit_vs_fp32_setting']      # the same forward
     out['tolerance'] = 'north_star: logits within 1e-3 of the reference; tests/test_gpu_model.py holds fp32 and bf16x3 to it on the golden vectors'
-    out['bf16x3']['how'] = ('float32 tensors; GEMM operands split into bf16 hi + lo on the bf16 MFMA kernels (csrc/x3.hip): the FORWARD keeps three terms '
-                            '(a_hi*w_hi + a_lo*w_hi + a_hi*w_lo: the logits the 1e-3 bar is about), the backward GEMMs two (filter rounded to bf16 in the data '
-                            'gradient, dz in the weight gradient: gradients 2-5e-3 relative L2 from the three-term backward, 1 - cosine <= 1.3e-5, same '
-                            'distance to the reference gradients; engine.x3_bwd_terms = 3 restores three: three_term_backward)')
+    out['bf16x3']['how'] = ('float32 tensors; GEMM operands split into bf16 hi + lo on the bf16 MFMA kernels, the split product fused into one reduction '
+                            '(csrc/conv3x3.hip X3, csrc/x3.hip): three terms (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo) in the forward AND in both backward GEMMs '
+                            '-- the parity setting')
+    out['bf16x3_fast']['how'] = ("precision='bf16x3-fast': the bf16x3 forward (the logits the 1e-3 bar is about) with TWO-term backward GEMMs (filter rounded to "
+                                 'bf16 in the data gradient, dz in the weight gradient): gradients 2-5e-3 relative L2 from the three-term backward, '
+                                 '1 - cosine <= 1.3e-5; an explicit opt-in, never the parity headline')
     out['fp32']['how'] = 'float32 tensors; v_mfma_f32_32x32x2_f32 (1/16 of the bf16 matrix rate)'
     return out
 
@@ -525,7 +529,7 @@ def val_f1_leg(dev, steps=60, B=8, S=128, lr=0.02):
     torch.manual_seed(1234)
     sd0 = {k: v.clone() for k, v in BiDateNet(13, 2).state_dict().items()}
     out = {}
-    for prec in ('fp32', 'bf16x3', 'bf16'):
+    for prec in ('fp32', 'bf16x3', 'bf16x3-fast', 'bf16'):
         m = BiDateNet(13, 2, precision=prec)
         m.load_state_dict(sd0)
         m = m.to(dev).train()
@@ -542,7 +546,7 @@ def val_f1_leg(dev, steps=60, B=8, S=128, lr=0.02):
                      'val_loss': float(v['cd_losses'])}
         del ts, m
         torch.cuda.empty_cache()
-    for prec in ('bf16x3', 'bf16'):
+    for prec in ('bf16x3', 'bf16x3-fast', 'bf16'):
         out[prec]['abs_dF1_vs_fp32'] = {'val': abs(out[prec]['val_f1'] - out['fp32']['val_f1']),
                                         'tail_train': abs(out[prec]['tail_train_f1'] - out['fp32']['tail_train_f1'])}
     out['workload'] = (f'{steps} fused train steps, batch {B}, 13-band {S}x{S} patches cut from 3 synthetic change-blob cities (lr {lr}, Tversky 0.1/0.9), '
@@ -668,7 +672,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='patch pairs per GPU')
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--channels', type=int, default=13)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'bf16x3-fast', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP events')
     ap.add_argument('--no-extras', action='store_true', help='skip the host_fed / parity_setting / scene legs')

@@ -211,17 +211,18 @@ class BiDateEngine:
 
     precision: 'bf16' (bf16 activations and packed weights, fp32 accumulate -- throughput setting), 'fp32' (f32 storage +
     f32 MFMA -- the exact parity setting, 1/16 of the bf16 matrix rate) or 'bf16x3' (f32 storage; every GEMM operand split into
-    bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate -- logits within 1e-3 of the reference at matrix-core speed).
+    bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate -- logits within 1e-3 of the reference at matrix-core speed);
+    'bf16x3-fast' is bf16x3 with two-term backward GEMMs (same forward, gradients 2-5e-3 relative L2 away).
     Same kernels: one template parameter, resp. a three times longer reduction for the bf16 kernels."""
 
     def __init__(self, n_channels, n_classes, precision='bf16'):
-        if precision not in ('bf16', 'fp32', 'bf16x3'):
-            raise ValueError(f"precision must be 'bf16', 'bf16x3' or 'fp32', got {precision!r}")
+        if precision not in ('bf16', 'fp32', 'bf16x3', 'bf16x3-fast'):
+            raise ValueError(f"precision must be 'bf16', 'bf16x3', 'bf16x3-fast' or 'fp32', got {precision!r}")
         self.n_channels, self.n_classes = n_channels, n_classes
         self.precision = precision
         self.dt = BDN_BF16 if precision == 'bf16' else BDN_F32                  # storage type: what the HBM-bound kernels see
-        self.mdt = BDN_BF16X3 if precision == 'bf16x3' else self.dt             # what the GEMM kernels (conv3x3, wgrad, weight packing) see
-        self.x3 = precision == 'bf16x3'
+        self.x3 = precision in ('bf16x3', 'bf16x3-fast')
+        self.mdt = BDN_BF16X3 if self.x3 else self.dt                           # what the GEMM kernels (conv3x3, wgrad, weight packing) see
         self.tdtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.esize = 2 if precision == 'bf16' else 4
         self.cp = _round_up(n_channels, 16)
@@ -255,11 +256,11 @@ class BiDateEngine:
         self.fwd_chain_levels = 3
         self._fwd_handoffs = {}
         self.wgrad_kernel = 0           # per-call kernel override of the weight-gradient GEMM (0 = the library's choice, _lib.WG_*)
-        # bf16x3 setting: terms of the split product in the BACKWARD GEMMs.  The forward always keeps three (logits within 1e-3 of the reference:
-        # north_star's bar); 2 (default, BDN_BF16X2) rounds the filter to bf16 in the data gradient and dz in the weight gradient -- the
-        # gradients move by 2-5e-3 relative L2 (1 - cosine <= 1.3e-5) against the three-term backward, their distance to the REFERENCE's
-        # gradients (1-4e-2 per parameter, float32-vs-float32 noise) does not, and the step is 17 % shorter; 3 = every GEMM three terms
-        self.x3_bwd_terms = 2
+        # bf16x3 settings: terms of the split product in the BACKWARD GEMMs.  The forward always keeps three (logits within 1e-3 of the reference:
+        # north_star's bar).  'bf16x3' (the parity setting) keeps three in the backward as well; 'bf16x3-fast' is the explicit opt-in to two
+        # (BDN_BF16X2: the filter rounded to bf16 in the data gradient, dz in the weight gradient) -- the gradients move by 2-5e-3 relative L2
+        # (1 - cosine <= 1.3e-5) against the three-term backward for a 15-17 % shorter step
+        self.x3_bwd_terms = 2 if precision == 'bf16x3-fast' else 3
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False

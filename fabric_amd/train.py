@@ -154,7 +154,7 @@ def main(argv=None):
         else:
             ap.add_argument(f'--{k}', type=type(v), default=v)
     ap.add_argument('--synthetic', action='store_true', help='use fabric_amd.utils.dataloaders.synthetic_onera()')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'bf16x3-fast', 'fp32'])
     ap.add_argument('--seed', type=int, default=0, help='seeds the shard permutation, the augmentation draws and the initial weights identically on every rank')
     ap.add_argument('--focal_gamma', type=float, default=None, help='required by --loss_function focal (utils/helpers.py:291)')
     ap.add_argument('--metadata', default=None, help="JSON in the reference's metadata.json schema (band_ids, band_means, "

@@ -168,6 +168,8 @@ class TrainStep:
         eng = self.model.engine()
         saved = saved_flat = None
         tried = []
+        from . import streams as _streams
+        orig_streams = (_streams.get('chain', dev), _streams.get('wgrad', dev))     # put back if a measurement raises half-way
         try:
             g = torch.Generator(device='cpu').manual_seed(99)
             C = self.model.n_channels
@@ -242,6 +244,10 @@ class TrainStep:
             self.bucketer.enabled = True
             if not ok:
                 self.bucketer.defer = False
+                # a measurement raised (OOM, RCCL error) while a remedy's stream was in place: back to the arrangement the guard started
+                # from -- the next guard must not start from a half-tried one (displaced streams are retired by restore, not leaked)
+                _streams.restore('chain', orig_streams[0], dev)
+                _streams.restore('wgrad', orig_streams[1], dev)
             self.bucketer.reset()
             torch.cuda.synchronize(dev)                    # chain-stream steps may still be in flight (exception path): restore after them
             if saved is not None and saved_flat is not None:

@@ -73,7 +73,7 @@ def strip_module_prefix(state_dict):
     return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
 
 
-def load_checkpoint(src, device=None, precision=None):
+def load_checkpoint(src, device=None, precision=None, allow_pickle=True):
     """A usable BiDateNet from anything the reference (or fabric_amd.train) leaves behind.
 
     `src` is a path / file object for torch.load, or an object already loaded:
@@ -82,11 +82,26 @@ def load_checkpoint(src, device=None, precision=None):
         sys.path).  The DataParallel wrapper is dropped: here one process drives one GPU (fabric_amd.parallel);
       * a state dict, with or without the `module.` prefix of a DataParallel save, optionally nested under 'state_dict' / 'model'.
     The result is always a fresh fabric_amd BiDateNet carrying the checkpoint's parameters AND BatchNorm buffers; the channel
-    counts come from the tensors.  Mismatched / missing / unexpected keys raise (load_state_dict(strict=True))."""
+    counts come from the tensors.  Mismatched / missing / unexpected keys raise (load_state_dict(strict=True)).
+
+    Trust: a file is first read with torch.load(weights_only=True) -- tensors and plain containers only, no code runs; that covers
+    every state-dict form (incl. the `*.state_dict.pt` fabric_amd.train writes for interchange).  Only when that loader refuses the
+    file (a whole-module pickle, train.py:222) is it unpickled in full, which EXECUTES whatever the pickle holds: pass
+    allow_pickle=False to refuse such files when the checkpoint does not come from a trusted source."""
     obj = src
     if isinstance(src, (str, bytes)) or hasattr(src, 'read') or hasattr(src, '__fspath__'):
-        # a whole-module pickle needs the unpickler, not the tensors-only loader
-        obj = torch.load(src, map_location='cpu', weights_only=False)
+        import pickle
+        pos = src.tell() if hasattr(src, 'tell') else None
+        try:
+            obj = torch.load(src, map_location='cpu', weights_only=True)
+        except (pickle.UnpicklingError, RuntimeError, AttributeError) as e:
+            # a whole-module pickle needs the unpickler, not the tensors-only loader
+            if not allow_pickle:
+                raise RuntimeError('fabric_amd: this checkpoint is a whole-module pickle (train.py:222); loading it executes the pickle -- '
+                                   'pass allow_pickle=True for files from a trusted source') from e
+            if pos is not None:
+                src.seek(pos)
+            obj = torch.load(src, map_location='cpu', weights_only=False)
     if isinstance(obj, torch.nn.DataParallel) or (isinstance(obj, torch.nn.Module) and hasattr(obj, 'module')
                                                   and not isinstance(obj, BiDateNet)):
         obj = obj.module
@@ -98,7 +113,7 @@ def load_checkpoint(src, device=None, precision=None):
             if nest in sd and isinstance(sd[nest], dict):
                 sd = sd[nest]
             elif nest in sd and isinstance(sd[nest], torch.nn.Module):
-                return load_checkpoint(sd[nest], device, precision)
+                return load_checkpoint(sd[nest], device, precision, allow_pickle)
     else:
         raise TypeError(f'fabric_amd: cannot load a checkpoint from {type(obj).__name__}')
     sd = strip_module_prefix(sd)
