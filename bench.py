@@ -278,7 +278,7 @@ def step_classes(ts, x1, x2, lbl, B, dev):
     chain, side = ts.stream().cuda_stream, streams.get('wgrad', dev).cuda_stream
     cls, queues = {}, {'q0_chain': 0.0, 'q1_wgrad': 0.0, 'other': 0.0}
     for name, phase, h, e0, e1 in raw:
-        c = _CLASS_OF.get(name) or (('conv_fwd' if phase == 'fwd' else 'conv_dgrad') if name == 'bdn_conv3x3' else 'hbm_bound')
+        c = _CLASS_OF.get(name) or (('conv_fwd' if phase == 'fwd' else 'conv_dgrad') if name in ('bdn_conv3x3', 'bdn_conv3x3_x3src') else 'hbm_bound')
         ms = e0.elapsed_time(e1)
         a = cls.setdefault(c, {'ms': 0.0, 'calls': 0})
         a['ms'] += ms; a['calls'] += 1

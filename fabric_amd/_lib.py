@@ -34,6 +34,7 @@ SIGNATURES = {
     'bdn_pack_weights': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'bdn_pack_weights_multi': (_i, [_i, _vp, _i, _vp]),
     'bdn_conv3x3': (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'bdn_conv3x3_x3src': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_num_mtiles': (_i, [_i, _i, _i, _i, _i]),
     'bdn_conv3x3_num_mtiles_ex': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'bdn_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -67,6 +67,12 @@ struct ConvArgs {
     //            maps, and neither date's activation reaches HBM.
     const float* ep_scale; const float* ep_shift; const void* ep_mul; void* ep_pool; int pair_stride;
     const float* cls_w; const float* cls_b; int cls_n; float* cls_logits; unsigned char* cls_mask; const int* cls_origins; int cls_H, cls_W;
+    // bf16x3 launches on a FLOAT32 source (template flag XF; round 6, bdn_conv3x3_x3src): in0 = the float32 tensor [N,H,W,C0] itself (ld0 = C0), in_bn
+    // its producer's BatchNorm table or null.  The staging applies relu(z * scale + shift) and splits the value into bf16 hi + lo on its way into the
+    // two LDS patches -- bdn_split_pack's arithmetic, element for element -- so no split pass runs in front of the convolution.  x3_split
+    // (optional, [N,H,W,2 C0] bf16 = hi | lo): the blocks of column tile 0 also store their tile's own pixels of the split operand there,
+    // for the layer's weight-gradient GEMM (what bdn_split_pack would have written).
+    void* x3_split;
 };
 
 template <typename T> struct Mma;
@@ -132,7 +138,7 @@ struct ConvCfg {
 // ONE: the whole reduction fits one channel chunk (Cin == CK: the 64-channel layers at full resolution).  Those
 // blocks are prologue/epilogue bound (144 MFMAs per wave), so the variant drops the next-chunk prefetch state and
 // is compiled for three blocks per CU instead of two.
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false, int X3 = 0>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false, int X3 = 0, bool XF = false>
 // blocks per CU the kernel is compiled for: three where the register budget of 168 holds without spilling
 // (single-chunk variant, 64-wide column tiles on 8-row spatial tiles), two otherwise
 // the multi-chunk 64-wide instantiation on 8 x 16 tiles needs 171 registers: at three blocks per CU (168) it spilled three of them;
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     static_assert(!BB || (sizeof(T) == 2 && sizeof(TO) == 2 && !D3 && TI == 1), "BatchNorm backward on load: bf16 2-D launches, one image per tile");
     static_assert(!EV || (!BB && !D3 && sizeof(T) == sizeof(TO)), "eval-mode epilogue: plain 2-D launches");
     static_assert(X3 == 0 || ((X3 == 2 || X3 == 3) && sizeof(T) == 2 && sizeof(TO) == 4 && CKB == 128 && !ONE && !D3 && !BB && !EV), "fused split product: bf16 operands, float32 outputs");
+    static_assert(!XF || X3 != 0, "float32-source staging belongs to the fused split product");
     uint4 preg[NPU];
     uint4 pregz[BB ? NPU : 1];                           // BB: the z units of the same pixels
 #define LOAD_PATCH(c0_)                                                                                  \
@@ -302,12 +309,51 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     uint4 pregl[X3 ? NPU : 1];
 #define X3_LOAD(c0_)                                                                                     \
     {                                                                                                   \
+        if constexpr (XF) {                                /* float32 source: a unit's eight channels are two 16-byte loads */ \
+            const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(reinterpret_cast<const float*>(a.in0) + (c0_)); \
+            const unsigned cb_ = (unsigned)a.ld0 * 4u;                                                  \
+            _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                            \
+                const unsigned o_ = (unsigned)(p_pix[i] >= 0 ? p_pix[i] : 0) * cb_ + p_subb * 2u;       \
+                preg[i] = *reinterpret_cast<const uint4*>(sb_ + o_);                                    \
+                pregl[i] = *reinterpret_cast<const uint4*>(sb_ + o_ + 16u);                             \
+            }                                                                                           \
+        } else {                                                                                        \
         const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(a.in0) + (c0_)); \
         const unsigned cb_ = (unsigned)a.ld0 * CF::ES, lo_ = (unsigned)a.C0 * CF::ES;                   \
         _Pragma("unroll") for (int i = 0; i < NPU; i++) {                                                \
             const unsigned o_ = (unsigned)(p_pix[i] >= 0 ? p_pix[i] : 0) * cb_ + p_subb;                \
             preg[i] = *reinterpret_cast<const uint4*>(sb_ + o_);                                        \
             pregl[i] = *reinterpret_cast<const uint4*>(sb_ + o_ + lo_);                                 \
+        }                                                                                               \
+        }                                                                                               \
+    }
+    // XF: unit i_ of the prefetched chunk c0_ in place, float32 z (preg = channels 0..3, pregl = 4..7) -> bf16 hi (preg) and lo (pregl) units --
+    // bdn_split_pack's arithmetic: v = relu(z * scale + shift), hi = bf16(v), lo = bf16(v - hi).  Run for one unit every other k-step in the
+    // middle of the PREVIOUS chunk's MFMAs (the loads have landed by then), so the ~50 VALU instructions per unit issue between
+    // MFMAs instead of in front of a barrier; the scale / shift rows come from the table the prologue left in LDS.
+#define X3_CONVERT(i_, c0_)                                                                              \
+    {                                                                                                   \
+        float f_[8], r_[8], g_[8];                                                                      \
+        Unit<float>::unpack(preg[i_], f_); Unit<float>::unpack(pregl[i_], f_ + 4);                      \
+        if (a.in_bn != nullptr) {                          /* block-uniform */                            \
+            const float* t_ = reinterpret_cast<const float*>(smem + 2 * CF::PATCH_BYTES) + (c0_) + p_sub; \
+            float xsc_[8], xsh_[8];                                                                     \
+            Unit<float>::unpack(*reinterpret_cast<const uint4*>(t_), xsc_); Unit<float>::unpack(*reinterpret_cast<const uint4*>(t_ + 4), xsc_ + 4); \
+            Unit<float>::unpack(*reinterpret_cast<const uint4*>(t_ + a.C0), xsh_); Unit<float>::unpack(*reinterpret_cast<const uint4*>(t_ + a.C0 + 4), xsh_ + 4); \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) f_[e] = fmaxf(fmaf(f_[e], xsc_[e], xsh_[e]), 0.f); \
+        }                                                                                               \
+        const uint4 h_ = Unit<bf16s>::pack(f_);                                                         \
+        Unit<bf16s>::unpack(h_, g_);                                                                    \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) r_[e] = f_[e] - g_[e];                             \
+        const uint4 l_ = Unit<bf16s>::pack(r_);                                                         \
+        preg[i_] = h_; pregl[i_] = l_;                                                                  \
+        if (a.x3_split != nullptr && ntile == 0 && p_pix[i_] >= 0) {      /* the tile's own pixels, once: the weight-gradient GEMM's operand */ \
+            const int u_ = tid + (i_) * 256, pix_ = u_ / UPP, xx_ = pix_ % TL::PW, yy_ = (pix_ / TL::PW) % TL::PH; \
+            if (xx_ >= 1 && xx_ <= TW && yy_ >= 1 && yy_ <= TH) {                                        \
+                unsigned char* so_ = reinterpret_cast<unsigned char*>(a.x3_split) + ((size_t)(unsigned)p_pix[i_] * (unsigned)(4 * a.C0) + (unsigned)(2 * (c0_)) + p_subb); \
+                *reinterpret_cast<uint4*>(so_) = h_;                                                    \
+                *reinterpret_cast<uint4*>(so_ + 2 * a.C0) = l_;                                         \
+            }                                                                                           \
         }                                                                                               \
     }
 #define X3_STORE()                                                                                       \
@@ -431,6 +477,16 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
         // rows [w_hi | w_hi | w_lo] of 3 C0 channels per tap: w_hi from the first third, w_lo from the last.
         constexpr int NSTEP = 9 * KG;
         static_assert(NSTEP % 3 == 0, "ring of three filter sets");
+        if constexpr (XF) {
+            if (a.in_bn != nullptr) {                                    // scale | shift rows of this block's statistic group, behind the two patches
+                float* tab = reinterpret_cast<float*>(smem + 2 * CF::PATCH_BYTES);
+                const float* ps = bn_row(a.in_bn, grp, 2, a.C0);         // rows 2 and 3 are consecutive: [scale(C0) | shift(C0)]
+                for (int i = tid * 4; i < 2 * a.C0; i += 1024) *reinterpret_cast<uint4*>(tab + i) = *reinterpret_cast<const uint4*>(ps + i);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < NPU; i++) X3_CONVERT(i, 0)               // the first chunk: nothing to hide behind yet
+        }
         const unsigned lo_rec = 2u * (unsigned)(a.C0 / KCH);             // record offset of w_lo inside a (cout block, tap) row
         int chunk = 0;
         for (int c0 = 0; c0 < a.C0; c0 += CK, chunk++) {
@@ -461,6 +517,11 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
             for (int s_ = 0; s_ < NSTEP; s_++) {
                 if (s_ + 2 < NSTEP) X3_LDB((s_ + 2) % 3, s_ + 2)
                 if (s_ + 1 < NSTEP) X3_LDA((s_ + 1) & 1, s_ + 1)
+                if constexpr (XF) {                                      // the next chunk's units, one every other k-step from step CV0 on
+                    constexpr int CV0 = 12;
+                    static_assert(CV0 + 2 * (NPU - 1) < NSTEP, "conversion steps inside the chunk");
+                    if (more && s_ >= CV0 && ((s_ - CV0) & 1) == 0 && (s_ - CV0) / 2 < NPU) X3_CONVERT((s_ - CV0) / 2 < NPU ? (s_ - CV0) / 2 : 0, c0 + CK)
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++)
@@ -507,6 +568,7 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     }
 #undef X3_LOAD
 #undef X3_STORE
+#undef X3_CONVERT
 #undef LDB
 #undef LOAD_R
 #undef STEP
@@ -858,21 +920,26 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
 static thread_local bool g_conv_query = false;
 static thread_local char g_conv_variant[160];
 
-template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false, int X3 = 0>
+template <typename T, int CKB, int TH, int TW, int TI, int BN, int WM, int WN, bool ONE = false, typename TO = T, bool D3 = false, bool BB = false, bool EV = false, int X3 = 0, bool XF = false>
 static int launch_conv(const ConvArgs& a, int n_mtiles, hipStream_t st) {
     using CF = ConvCfg<T, CKB, TH, TW, TI, BN, WM, WN, !ONE, TO, X3>;
     if (g_conv_query) {
         // the full template spelling, so that a profiler can match rocprofv3's kernel names exactly ("bf16" = unsigned short)
-        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s,%s,%d>",
+        snprintf(g_conv_variant, sizeof(g_conv_variant), "conv3x3_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%s,%s,%s,%s,%s,%d,%s>",
                  sizeof(T) == 2 ? "bf16" : "float", CKB, TH, TW, TI, BN, WM, WN, ONE ? "true" : "false",
-                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false", EV ? "true" : "false", X3);
+                 sizeof(TO) == 2 ? "bf16" : "float", D3 ? "true" : "false", BB ? "true" : "false", EV ? "true" : "false", X3, XF ? "true" : "false");
         return BDN_OK;
     }
-    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB, EV, X3>;
-    BDN_SET_SMEM_ONCE(kern, CF::SMEM, "conv3x3");
+    auto kern = conv3x3_kernel<T, CKB, TH, TW, TI, BN, WM, WN, ONE, TO, D3, BB, EV, X3, XF>;
+    // XF: the BatchNorm scale | shift rows of the operand's channels sit behind the two patches (<= 4 KB: C0 <= 512, checked by the entry point)
+    constexpr int XF_TAB_MAX = XF ? 4096 : 0;
+    constexpr int SMEM_MAX = (CF::MAIN_BYTES + XF_TAB_MAX > CF::SMEM) ? CF::MAIN_BYTES + XF_TAB_MAX : CF::SMEM;
+    BDN_SET_SMEM_ONCE(kern, SMEM_MAX, "conv3x3");
+    const int xf_tab = XF ? 2 * a.C0 * 4 : 0;
+    const int smem_bytes = (CF::MAIN_BYTES + xf_tab > CF::SMEM) ? CF::MAIN_BYTES + xf_tab : CF::SMEM;
     ConvArgs b = a;
     b.n_ntiles = a.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3(n_mtiles * b.n_ntiles), dim3(256), CF::SMEM, st, b);
+    hipLaunchKernelGGL(kern, dim3(n_mtiles * b.n_ntiles), dim3(256), smem_bytes, st, b);
     BDN_CHECK_LAUNCH("conv3x3");
     return BDN_OK;
 }
@@ -951,12 +1018,12 @@ static ConvPlan conv_plan_x3f(int N, int H, int W, int Cout, int imgs_per_group)
     return p;
 }
 
-template <int X3>
+template <int X3, bool XF = false>
 static int dispatch_conv_x3f(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
-    if (g.TI == 1 && p.BN == 128) return launch_conv<bf16s, 128, 8, 16, 1, 128, 1, 4, false, float, false, false, false, X3>(a, g.n_mtiles, st);
-    if (g.TI == 1) return launch_conv<bf16s, 128, 8, 16, 1, 64, 2, 2, false, float, false, false, false, X3>(a, g.n_mtiles, st);
-    return launch_conv<bf16s, 128, 8, 8, 2, 64, 2, 2, false, float, false, false, false, X3>(a, g.n_mtiles, st);
+    if (g.TI == 1 && p.BN == 128) return launch_conv<bf16s, 128, 8, 16, 1, 128, 1, 4, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
+    if (g.TI == 1) return launch_conv<bf16s, 128, 8, 16, 1, 64, 2, 2, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
+    return launch_conv<bf16s, 128, 8, 8, 2, 64, 2, 2, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
 }
 
 // tiles of a launch by operand type: the bf16x3 kernels with the fused split product (C0 a multiple of 64) have their own tile plan
@@ -1011,7 +1078,7 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.bb_z = bb_z; a.bb_bn = bb_bn; a.bb_sums = bb_sums; a.bb_dz = bb_dz; a.bb_invM = 1.f / (float)((size_t)imgs_per_group * H * W);
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
-    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0; a.x3_split = nullptr;
     const bool x3f = BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) && C0 % 64 == 0;
     const ConvPlan g = x3f ? conv_plan_x3f(N, H, W, Cout, imgs_per_group) : conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
@@ -1054,6 +1121,40 @@ extern "C" const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C
                                 nullptr, nullptr, nullptr, N, H, W, Cout, nullptr);
     g_conv_query = false;
     return rc == BDN_OK ? g_conv_variant : "";
+}
+
+// bf16x3 / bf16x2 convolution on a FLOAT32 operand (round 6): what bdn_split_pack(in, BNRELU / PLAIN) + bdn_conv3x3(BDN_BF16X3) compute, in one
+// launch -- the staging applies relu(z * scale + shift) and the bf16 hi / lo split on the way into LDS (models/unet_parts.py:14-16: BatchNorm ->
+// ReLU -> Conv2d).  in [N,H,W,C0] float32, C0 a multiple of 64 and <= 512; w the bdn_pack_weights(BDN_BF16X3) image; out float32.
+// split_out: NULL, or [N,H,W,2 C0] bf16 that receives exactly bdn_split_pack's output (the layer's weight-gradient GEMM reads it).
+extern "C" int bdn_conv3x3_x3src(int dtype, const float* in, int C0, int in_mode, const float* in_bn, int imgs_per_group,
+                                 const void* w, const float* bias, float* out, float* stats_partial, void* split_out,
+                                 int N, int H, int W, int Cout, void* stream) {
+    if (!in || !w || !out) BDN_FAIL(BDN_E_ARG, "conv3x3_x3src: null pointer");
+    if (dtype != BDN_BF16X3 && dtype != BDN_BF16X2) BDN_FAIL(BDN_E_ARG, "conv3x3_x3src: bad dtype %d (bf16x3 / bf16x2)", dtype);
+    if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
+        BDN_FAIL(BDN_E_SHAPE, "conv3x3_x3src: bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
+    if (Cout <= 0 || Cout % 64) BDN_FAIL(BDN_E_SHAPE, "conv3x3_x3src: Cout=%d must be a multiple of 64", Cout);
+    if (C0 <= 0 || C0 % 64 || C0 > 512) BDN_FAIL(BDN_E_SHAPE, "conv3x3_x3src: C0=%d must be a multiple of 64, at most 512", C0);
+    if (in_mode != BDN_IN_BNRELU && in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3x3_x3src: bad in_mode %d", in_mode);
+    if (in_mode == BDN_IN_BNRELU && !in_bn) BDN_FAIL(BDN_E_ARG, "conv3x3_x3src: BNRELU input needs in_bn");
+    const size_t npix = (size_t)N * H * W;
+    if (npix * (size_t)C0 * 4 >= ((size_t)1 << 32) || npix * (size_t)Cout * 4 >= ((size_t)1 << 32))
+        BDN_FAIL(BDN_E_SHAPE, "conv3x3_x3src: a tensor of N*H*W=%zu pixels reaches 4 GB; split the batch", npix);
+    ConvArgs a;
+    a.in0 = in; a.in1 = nullptr; a.C0 = C0; a.C1 = 0; a.ld0 = C0; a.ld1 = 0; a.in2 = nullptr; a.Dz = 0;
+    a.w_kgroups = 3 * C0 / 16;
+    a.in_bn = in_mode == BDN_IN_BNRELU ? in_bn : nullptr;
+    a.imgs_per_group = imgs_per_group; a.w = w; a.bias = bias; a.out = out; a.stats_partial = stats_partial;
+    a.bs_z = nullptr; a.bs_bn = nullptr; a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
+    a.x3_split = split_out;
+    const ConvPlan g = conv_plan_x3f(N, H, W, Cout, imgs_per_group);
+    a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == BDN_BF16X3 ? dispatch_conv_x3f<3, true>(a, g, st) : dispatch_conv_x3f<2, true>(a, g, st);
 }
 
 extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad, void* dA,
@@ -1117,7 +1218,7 @@ static int conv3x3_eval_impl(int dtype, const void* in0, int C0, const void* in1
     a.bs_z = nullptr; a.bs_bn = nullptr; a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mul = mul; a.ep_pool = pool; a.pair_stride = 0;
-    a.cls_w = cls_w; a.cls_b = cls_b; a.cls_n = ncls; a.cls_logits = logits; a.cls_mask = mask; a.cls_origins = origins; a.cls_H = Hs; a.cls_W = Ws;
+    a.cls_w = cls_w; a.cls_b = cls_b; a.cls_n = ncls; a.cls_logits = logits; a.cls_mask = mask; a.cls_origins = origins; a.cls_H = Hs; a.cls_W = Ws; a.x3_split = nullptr;
     // no statistic groups in eval mode: two images of a small map may always share a tile
     const ConvPlan g = conv_plan(N, H, W, Cout, N % 2 == 0 ? 2 : 1);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
@@ -1184,7 +1285,7 @@ extern "C" int bdn_conv3x3_eval_pair(int dtype, const void* in, int C0, const vo
     a.bs_z = nullptr; a.bs_bn = nullptr; a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
     a.N = 2 * B; a.H = H; a.W = W; a.Cout = Cout;
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_mul = nullptr; a.ep_pool = pool; a.pair_stride = B;
-    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0; a.x3_split = nullptr;
     const ConvPlan g = conv_plan_pair(B, H, W, Cout);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1255,7 +1356,7 @@ extern "C" int bdn_conv3d(int dtype, const void* in, int C, int in_mode, const f
     a.N = N * D; a.H = H; a.W = W; a.Cout = Cout;
     a.bb_z = nullptr; a.bb_bn = nullptr; a.bb_sums = nullptr; a.bb_dz = nullptr; a.bb_invM = 0.f;
     a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
-    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0;
+    a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0; a.x3_split = nullptr;
     const ConvPlan p = conv3d_plan(N * D, H, W, Cout);
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

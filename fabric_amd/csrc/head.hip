@@ -27,6 +27,23 @@ __global__ void pack_input_kernel(const float* __restrict__ x1, const float* __r
     *reinterpret_cast<uint4*>(out + ((size_t)n * hw + p) * Cpad + u * EPU) = Unit<T>::pack(f);
 }
 
+// bf16x3: the packed input leaves directly as the [hi | lo] bf16 operand of the first convolution ([2B,H,W,2 Cpad]: bdn_split_pack's layout)
+__global__ void pack_input_split_kernel(const float* __restrict__ x1, const float* __restrict__ x2, bf16s* __restrict__ out,
+                                        int B, int C, int H, int W, int Cpad, FastDiv dhw, FastDiv dupp) {
+    const int upp = Cpad / 4;
+    const size_t hw = (size_t)H * W, total = (size_t)2 * B * hw * upp;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int ti, pi, n, u; dhw.divmod((int)i, ti, pi); dupp.divmod(ti, n, u);
+    const size_t p = pi;
+    const float* src = (n < B ? x1 + (size_t)n * C * hw : x2 + (size_t)(n - B) * C * hw) + p;
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const int c = u * 4 + e; f[e] = c < C ? src[(size_t)c * hw] : 0.f; }
+    const SplitOut so = {out, 2 * Cpad, 0, Cpad};
+    store_split4(so, (size_t)n * hw + p, u * 4, f);
+}
+
 extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,
                               int B, int C, int H, int W, int Cpad, void* stream) {
     if (!x_d1 || !x_d2 || !out) BDN_FAIL(BDN_E_ARG, "pack_input: null pointer");
@@ -36,6 +53,7 @@ extern "C" int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, v
     if (npix * (Cpad / 4) >= ((size_t)1 << 31)) BDN_FAIL(BDN_E_SHAPE, "pack_input: 2*B*H*W*Cpad/4 = %zu reaches 2^31; split the batch", npix * (Cpad / 4));
     if (dtype == BDN_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16s>, dim3(grid_for(npix * (Cpad / 8))), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad, FastDiv(H * W), FastDiv(Cpad / 8));
     else if (dtype == BDN_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(npix * (Cpad / 4))), dim3(256), 0, st, x_d1, x_d2, (float*)out, B, C, H, W, Cpad, FastDiv(H * W), FastDiv(Cpad / 4));
+    else if (dtype == BDN_BF16X3) hipLaunchKernelGGL(pack_input_split_kernel, dim3(grid_for(npix * (Cpad / 4))), dim3(256), 0, st, x_d1, x_d2, (bf16s*)out, B, C, H, W, Cpad, FastDiv(H * W), FastDiv(Cpad / 4));
     else BDN_FAIL(BDN_E_ARG, "pack_input: bad dtype");
     BDN_CHECK_LAUNCH("pack_input");
     return BDN_OK;
@@ -464,7 +482,7 @@ extern "C" int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, cons
 // dlogits (ncls values per pixel) instead of read back: dA = round_T(sum_k dl[k] w[k][c]) exactly as outc_bwd forms and
 // rounds it, then bn_bwd_apply's expression.  outc_bwd then need not store dA at all: 2 x B*H*W*C elements of HBM traffic
 // less, at a point of the step where nothing else runs.
-template <typename T, int NC>
+template <typename T, int NC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __restrict__ dl, const float* __restrict__ w,
                                 const T* __restrict__ z, const float* __restrict__ bn, const float* __restrict__ sums,
                                 T* __restrict__ dz, int npix, int hw, int pix_per_group, int pix_per_block, int C, int ncls, FastDiv dhw, FastDiv dppg) {
@@ -521,6 +539,10 @@ __global__ __launch_bounds__(256) void outc_bn_bwd_apply_kernel(const float* __r
                 const float xhat = (fz[i] - mean[i]) * inv[i];
                 o[i] = sc[i] * (gm - k0[i] - xhat * k1[i]);
             }
+            if constexpr (SPLIT) {                             // bf16x3: dz leaves as the [hi | lo] operand of its two consumers ([pixel][2C])
+                const SplitOut so = {reinterpret_cast<bf16s*>(dz), 2 * C, 0, C};
+                store_split4(so, (size_t)p, c, o);
+            } else
             *reinterpret_cast<uint4*>(dz + (size_t)p * C + c) = Unit<T>::pack(o);
         }
     }
@@ -535,6 +557,14 @@ extern "C" int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const floa
     const int npix = B * H * W, epu = dtype == BDN_BF16 ? 8 : 4, rows = 256 / (C / epu);
     int ppb = (npix + 2047) / 2048; if (ppb < 2 * rows) ppb = 2 * rows; ppb = (ppb + rows - 1) / rows * rows;
     const unsigned grid = (npix + ppb - 1) / ppb;
+    if (dtype == BDN_BF16X3) {                 // float32 z, dz stored as the split operand
+#define OUTC_APPLY_S(NC_) hipLaunchKernelGGL((outc_bn_bwd_apply_kernel<float, NC_, true>), dim3(grid), dim3(256), 0, st, dlogits, w, (const float*)z, bn, sums, \
+                                               (float*)dz, npix, H * W, imgs_per_group * H * W, ppb, C, ncls, FastDiv(H * W), FastDiv(imgs_per_group * H * W))
+        if (ncls <= 2) OUTC_APPLY_S(2); else OUTC_APPLY_S(OUTC_MAXCLS);
+#undef OUTC_APPLY_S
+        BDN_CHECK_LAUNCH("outc_bn_bwd_apply");
+        return BDN_OK;
+    }
 #define OUTC_APPLY(T_, NC_) hipLaunchKernelGGL((outc_bn_bwd_apply_kernel<T_, NC_>), dim3(grid), dim3(256), 0, st, dlogits, w, (const T_*)z, bn, sums, \
                                                (T_*)dz, npix, H * W, imgs_per_group * H * W, ppb, C, ncls, FastDiv(H * W), FastDiv(imgs_per_group * H * W))
     if (dtype == BDN_BF16) { if (ncls <= 2) OUTC_APPLY(bf16s, 2); else OUTC_APPLY(bf16s, OUTC_MAXCLS); }

@@ -159,6 +159,7 @@ class Workspace:
         self._split = {}
         self._outc_ws = None
         self.logits = None
+        self.x0_split = False      # bf16x3: the last pack_input stored the first convolution's split operand instead of x0
         self.leased = False        # True while a live autograd graph still needs this workspace's z / bn tables for its backward
         self.generation = 0        # bumped by every forward that overwrites the buffers (models/bidate_model.py checks it before a backward)
 
@@ -261,6 +262,16 @@ class BiDateEngine:
         # (BDN_BF16X2: the filter rounded to bf16 in the data gradient, dz in the weight gradient) -- the gradients move by 2-5e-3 relative L2
         # (1 - cosine <= 1.3e-5) against the three-term backward for a 15-17 % shorter step
         self.x3_bwd_terms = 2 if precision == 'bf16x3-fast' else 3
+        # bf16x3: convolutions whose operand is ONE float32 tensor of 64...512 channels (the second convolution of every double_conv) read it
+        # directly -- BatchNorm+ReLU and the hi / lo split inside the staging (bdn_conv3x3_x3src), the split operand left for the weight gradient
+        # as a by-product -- instead of behind a bdn_split_pack pass.  Each launch alone at B = 64 (tools/bench_x3_conv.py, us: split pass +
+        # convolution -> one launch):  e1b 619 -> 690  e2b 444 -> 442  e3b 373 -> 397  e4b 345 -> 374  e5b 97 -> 103  d1b 53 -> 53  d2b 64 -> 64
+        # d3b 83 -> 70  d4b 326 -> 273: the split pass streams at 5.9 TB/s and the conversion is ~50 VALU instructions per 16-byte unit of an
+        # issue-bound kernel, so alone the sum is a wash (2.40 vs 2.47 ms).  IN the step (tools/ab_cfg.py, three-term backward, one process):
+        # none 14.875 ms, d3b+d4b only 14.863, every eligible layer 14.838 (-0.25 %) -- the passes it removes ran beside the weight-gradient
+        # queue.  True = every eligible layer (no split pass left in a step), a tuple of layer names = only those (eval forwards then take it
+        # for operands of <= 128 channels), False = none (rounds 3-5; the checker of the fused form in tests)
+        self.x3_src_f32 = True
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
@@ -395,17 +406,28 @@ class BiDateEngine:
             z, bn = z[date * n:(date + 1) * n], bn[date:date + 1]
             if date == 1:
                 stats, bnws = ws.chain2()
-        if self.x3:
-            # the operand split does the cat and the BatchNorm+ReLU the f32 kernel would apply on load
-            # training: one buffer per layer, kept for the layer's weight-gradient GEMM (the same operand: no second split in backward)
-            sp = ws.split_buf(('a', L.name) if training else 'a', n * hk * wk * 2 * (c0 + c1))
-            if not presplit:                         # presplit: the producers of the operand (product_pool / upsample2x) stored it split already
-                call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
-            in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
-        self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
-                         self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
-                         ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(stats) if training else None,
-                         n, hk, wk, L.cout, st)
+        xs = self.x3_src_f32
+        if self.x3 and in1 is None and not presplit and c0 % 64 == 0 and c0 <= 512 and xs and \
+                (not isinstance(xs, (tuple, list, set)) or L.name in xs or (not training and c0 <= 128)):
+            # one float32 source of >= 64 channels (the second convolution of every double_conv): BatchNorm+ReLU and the hi / lo split are
+            # applied inside the convolution's staging (bdn_conv3x3_x3src); in training the tile's own pixels of the split operand are
+            # stored as a by-product for the layer's weight-gradient GEMM -- no bdn_split_pack launch
+            sp = ws.split_buf(('a', L.name), n * hk * wk * 2 * c0) if training else None
+            self._timed_conv(n, hk, wk, c0, 0, L.cout, ipg,
+                             self.mdt, ptr(in0), c0, in_mode, ptr(in_bn), ipg, ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z),
+                             ptr(stats) if training else None, ptr(sp), n, hk, wk, L.cout, st, fn='bdn_conv3x3_x3src')
+        else:
+            if self.x3:
+                # the operand split does the cat and the BatchNorm+ReLU the f32 kernel would apply on load
+                # training: one buffer per layer, kept for the layer's weight-gradient GEMM (the same operand: no second split in backward)
+                sp = ws.split_buf(('a', L.name) if training else 'a', n * hk * wk * 2 * (c0 + c1))
+                if not presplit:                         # presplit: the producers of the operand (product_pool / upsample2x) stored it split already
+                    call('bdn_split_pack', ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg, ptr(sp), n, hk, wk, st)
+                in0, c0, in1, c1, in_mode, in_bn = sp, c0 + c1, None, 0, IN_PLAIN, None
+            self._timed_conv(n, hk, wk, c0, c1, L.cout, ipg,
+                             self.mdt, ptr(in0), c0, ptr(in1), c1, in_mode, ptr(in_bn), ipg,
+                             ptr(wf), ptr(P[f'{L.conv}.bias']), ptr(z), ptr(stats) if training else None,
+                             n, hk, wk, L.cout, st)
         G = n // ipg
         if training:
             nt = self.mtiles(n, hk, wk, c0 + c1, L.cout, ipg)
@@ -439,7 +461,12 @@ class BiDateEngine:
         B, C, H, W = x_d1.shape
         ws = self.workspace(B, H, W, x_d1.device)
         ws.generation += 1
-        call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, _lib.stream_ptr())
+        ws.x0_split = self.x3 and not class_map
+        if ws.x0_split:            # bf16x3: the packed input leaves as the first convolution's [hi | lo] operand (no float32 x0, no split pass)
+            sp = ws.split_buf(('a', self.layers[0].name) if training else 'a', 2 * B * H * W * 2 * self.cp)
+            call('bdn_pack_input', BDN_BF16X3, ptr(x_d1), ptr(x_d2), ptr(sp), B, C, H, W, self.cp, _lib.stream_ptr())
+        else:
+            call('bdn_pack_input', self.dt, ptr(x_d1), ptr(x_d2), ptr(ws.x0), B, C, H, W, self.cp, _lib.stream_ptr())
         if class_map:
             if training:
                 raise RuntimeError('class_map=True is an eval-mode output')
@@ -471,6 +498,7 @@ class BiDateEngine:
         n, p = origins.shape[0], patch_size
         ws = self.workspace(n, p, p, scene_d1.device, slot)
         ws.generation += 1
+        ws.x0_split = False
         call('bdn_gather_tiles', self.dt, ptr(scene_d1), ptr(scene_d2), ptr(origins), ptr(ws.x0),
              n, C, H, W, p, self.cp, _lib.stream_ptr())
         if scene_mask is not None:
@@ -509,7 +537,8 @@ class BiDateEngine:
             La, Lb = by[f'e{k}a'], by[f'e{k}b']
             pre = self.x3 and training                      # bf16x3 training: pooled maps, skips and upsampled maps are stored as split operands
             src = ws.x0 if k == 1 else (None if pre else ws.pool[k])   # pool[k] was written together with the skip of level k-1
-            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb, presplit=pre and k > 1)
+            za, bna = self._conv(ws, La, P, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, training, st, rb,
+                                 presplit=(pre and k > 1) or (k == 1 and ws.x0_split))
             zb, bnb = self._conv(ws, Lb, P, za, Lb.cin, None, 0, IN_BNRELU, bna, 2 * B, B, training, st, rb)
             if k < 5 and pre:
                 Ld, Ln = by[f'd{5 - k}a'], by[f'e{k + 1}a']
@@ -899,11 +928,13 @@ class BiDateEngine:
             cprev = La.cin - ck
             folded_b = False
             if j == 4:
-                dzb = e(B, hk, wk, Lb.cout)
+                # bf16x3: dz leaves the pass as the [hi | lo] operand of its two consumers (no float32 dz, no split pass over it)
+                dzb = None if self.x3 else e(B, hk, wk, Lb.cout)
+                dz_out = ws.split_buf(('d', Lb.name), B * hk * wk * 2 * Lb.cout) if self.x3 else dzb
                 call('bdn_bn_bwd_finalize', ptr(ws.bn[Lb.name]), 1, Lb.cout, ptr(ws.stats), rows_head, 1, ptr(sc['sums']),
                      ptr(grads[f'{Lb.bn}.weight']), ptr(grads[f'{Lb.bn}.bias']), ptr(ws.bnws), st)
-                call('bdn_outc_bn_bwd_apply', self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
-                     ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dzb), B, hk, wk, Lb.cout, self.n_classes, st)
+                call('bdn_outc_bn_bwd_apply', self.mdt if self.x3 else self.dt, ptr(dlogits), ptr(P['outc.conv.weight']), ptr(ws.z[Lb.name]),
+                     ptr(ws.bn[Lb.name]), B, ptr(sc['sums']), ptr(dz_out), B, hk, wk, Lb.cout, self.n_classes, st)
             elif Lb.name in fold and rows_up and ldA == Lb.cout == 64 and min(hk, wk) > 8:
                 dzb, dAa, rows = fold_dgrad(Lb, dA_ptr, B, B, rows_up, prev=La)
                 folded_b = True

@@ -59,7 +59,8 @@ int bdn_event_record(void* event, void* stream);
 int bdn_stream_wait_event(void* stream, void* event);
 
 /* ---- layout converters (boundary of BiDateNet.forward, models/bidate_model.py:22) ---- */
-/* x_d1, x_d2: [B,C,H,W] f32 NCHW  ->  out: [2B,H,W,Cpad] (date-1 images first), channels >= C zeroed. */
+/* x_d1, x_d2: [B,C,H,W] f32 NCHW  ->  out: [2B,H,W,Cpad] (date-1 images first), channels >= C zeroed.
+ * dtype BDN_BF16X3: out is the first convolution's split operand [2B,H,W,2 Cpad] bf16 = hi | lo (bdn_split_pack of the float32 image). */
 int bdn_pack_input(int dtype, const float* x_d1, const float* x_d2, void* out,
                    int B, int C, int H, int W, int Cpad, void* stream);
 /* OIHW f32 [Cout,Cin,3,3] -> forward GEMM image wf [Cout][9][Cin_pad] and the data-gradient image
@@ -94,6 +95,16 @@ int bdn_conv3x3_num_mtiles_ex(int dtype, int N, int H, int W, int C0, int Cout, 
 /* Name of the kernel instantiation bdn_conv3x3 runs for a shape, e.g. "conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false>"
  * (the rocprofv3 name with `unsigned short` spelled bf16); "" for an unsupported shape.  Thread-local buffer. */
 const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, int Cout, int imgs_per_group);
+
+/* bf16x3 / bf16x2 convolution straight from a FLOAT32 operand (reference: models/unet_parts.py:14-16, BatchNorm -> ReLU -> Conv2d of a
+ * double_conv's second half; round 6).  Equals bdn_split_pack(in, in_mode, in_bn) followed by bdn_conv3x3(dtype, ...) bit for bit, in one
+ * launch: relu(z * scale + shift) and the bf16 hi / lo split are applied while the tile is staged, no split pass runs in front of the
+ * convolution.  in [N,H,W,C0] float32, C0 a multiple of 64 and <= 512; w the bdn_pack_weights(BDN_BF16X3) forward image; out float32;
+ * stats_partial as bdn_conv3x3 with bdn_conv3x3_num_mtiles_ex(dtype, ...) rows.
+ * split_out: NULL, or [N,H,W,2 C0] bf16 that receives exactly bdn_split_pack's output (the layer's weight-gradient GEMM reads it later). */
+int bdn_conv3x3_x3src(int dtype, const float* in, int C0, int in_mode, const float* in_bn, int imgs_per_group,
+                      const void* w, const float* bias, float* out, float* stats_partial, void* split_out,
+                      int N, int H, int W, int Cout, void* stream);
 
 /* Data gradient of nn.Conv2d(ci,co,3,padding=1) (autograd of models/unet_parts.py:13,16) with the BatchNorm-backward
  * statistics of the PRODUCING layer fused into the epilogue: dz [N,H,W,C0] x rotated filter image w_dgrad ->
@@ -349,7 +360,8 @@ int bdn_outc_bwd(int dtype, const float* dlogits, const void* z, const float* bn
 /* BatchNorm+ReLU backward of the layer in front of the classifier with the classifier's data gradient recomputed from
  * dlogits (outconv, models/unet_parts.py:83-90, after double_conv's BN+ReLU, :16-18): dz = bn_bwd(round(sum_k dlogits[k] w[k][c]), z)
  * with `sums` from bdn_bn_bwd_finalize.  Call bdn_outc_bwd with dA = NULL (it still leaves the partial sums) and this instead
- * of bdn_bn_bwd_apply: the gradient tensor in between is never written or read. */
+ * of bdn_bn_bwd_apply: the gradient tensor in between is never written or read.
+ * dtype BDN_BF16X3: z float32, dz the split operand [B,H,W,2 C] bf16 = hi | lo of the float32 result (bdn_bn_bwd_apply_split's form). */
 int bdn_outc_bn_bwd_apply(int dtype, const float* dlogits, const float* w, const void* z, const float* bn,
                           int imgs_per_group, const float* sums, void* dz, int B, int H, int W, int C, int ncls, void* stream);
 /* bs_partial: NULL, or f32 [bdn_outc_bwd_rows(dtype,B,H,W,C)][2][C]: BatchNorm-backward partial sums of the layer that

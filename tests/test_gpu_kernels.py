@@ -1007,6 +1007,55 @@ def test_conv3x3_bf16x3_forward_dgrad_wgrad(case):
     assert_close('x3 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz, padding=1), 1e-4)
 
 
+@pytest.mark.parametrize('dtype', ['x3', 'x2'])
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 1, True), (4, 8, 8, 128, 64, 2, True), (3, 19, 33, 64, 128, 3, True), (2, 12, 12, 192, 64, 2, False),
+                                  (36, 32, 32, 128, 256, 18, True), (2, 8, 8, 512, 128, 1, True), (2, 40, 72, 64, 64, 1, True)])
+def test_conv3x3_x3src_equals_split_pack_then_conv(case, dtype):
+    """bdn_conv3x3_x3src (float32 operand; BatchNorm+ReLU and the bf16 hi / lo split inside the convolution's staging -- models/unet_parts.py:14-16)
+    against the two launches it replaces, bdn_split_pack + bdn_conv3x3 on the split operand: output, statistics partials and the split operand it
+    leaves for the weight-gradient GEMM are all bit-identical; and the float32 oracle holds within 1e-4 (three terms)."""
+    N, H, W, Cin, Cout, ipg, use_bn = case
+    lib = _lib.load()
+    DT = _lib.BDN_BF16X3 if dtype == 'x3' else _lib.BDN_BF16X2
+    x = _rand((N, Cin, H, W), 711)
+    w = _rand((Cout, Cin, 3, 3), 712) * 0.1
+    b = _rand((Cout,), 713)
+    bn = bn_table(N // ipg, Cin, 714)
+    xd, bn_d, bd, wdev = to_nhwc('fp32', x), dev(bn), dev(b), dev(w)
+    mode = IN_BNRELU if use_bn else IN_PLAIN
+    wf = torch.empty(Cout, 9, 3 * Cin, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_pack_weights', _lib.BDN_BF16X3, wdev.data_ptr(), wf.data_ptr(), None, Cout, Cin, Cin, st())
+    nt = lib.bdn_conv3x3_num_mtiles_ex(DT, N, H, W, Cin, Cout, ipg)
+    # the two launches
+    sp = torch.empty(N, H, W, 2 * Cin, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', xd.data_ptr(), Cin, None, 0, mode, bn_d.data_ptr(), ipg, sp.data_ptr(), N, H, W, st())
+    out0 = torch.full((N, H, W, Cout), float('nan'), device='cuda')
+    st0 = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    _lib.call('bdn_conv3x3', DT, sp.data_ptr(), Cin, None, 0, IN_PLAIN, None, ipg, wf.data_ptr(), bd.data_ptr(), out0.data_ptr(),
+              st0.data_ptr(), N, H, W, Cout, st())
+    # the one launch
+    sp1 = torch.full((N, H, W, 2 * Cin), float('nan'), dtype=torch.bfloat16, device='cuda')
+    out1 = torch.full((N, H, W, Cout), float('nan'), device='cuda')
+    st1 = torch.full((nt, 2, Cout), float('nan'), device='cuda')
+    _lib.call('bdn_conv3x3_x3src', DT, xd.data_ptr(), Cin, mode, bn_d.data_ptr(), ipg, wf.data_ptr(), bd.data_ptr(), out1.data_ptr(),
+              st1.data_ptr(), sp1.data_ptr(), N, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert torch.equal(sp1.view(torch.int16), sp.view(torch.int16))
+    assert torch.equal(out1, out0) and torch.equal(st1, st0)
+    # without the by-product (eval forwards), same output
+    out2 = torch.full((N, H, W, Cout), float('nan'), device='cuda')
+    _lib.call('bdn_conv3x3_x3src', DT, xd.data_ptr(), Cin, mode, bn_d.data_ptr(), ipg, wf.data_ptr(), bd.data_ptr(), out2.data_ptr(),
+              None, None, N, H, W, Cout, st())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out0)
+    if dtype == 'x3':
+        a = bnrelu_ref('fp32', x, bn, ipg) if use_bn else x
+        assert_close('x3src fwd', from_nhwc(out1), F.conv2d(a, w, b, padding=1), 1e-4)
+    with pytest.raises(RuntimeError):          # operands the staging table does not hold
+        _lib.call('bdn_conv3x3_x3src', DT, xd.data_ptr(), 1024, mode, bn_d.data_ptr(), ipg, wf.data_ptr(), bd.data_ptr(), out2.data_ptr(),
+                  None, None, N, H, W, Cout, st())
+
+
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 1), (2, 8, 8, 128, 64, 2), (3, 19, 33, 64, 128, 3), (2, 12, 12, 192, 64, 2)])
 def test_conv3x3_bf16x2_backward_gemms(case):
     """BDN_BF16X2, the two-term backward of the bf16x3 setting, on the operands and filter images of BDN_BF16X3: the data gradient equals
@@ -1044,6 +1093,46 @@ def test_conv3x3_bf16x2_backward_gemms(case):
               part.data_ptr(), dw.data_ptr(), Cin, N, H, W, st())
     torch.cuda.synchronize()
     assert_close('x2 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz_hi, padding=1), 1e-4)
+
+
+def test_pack_input_and_head_bn_bwd_store_the_split_operand_directly():
+    """bf16x3 setting, round 6: bdn_pack_input(BDN_BF16X3) and bdn_outc_bn_bwd_apply(BDN_BF16X3) store what bdn_split_pack would make of their
+    float32 outputs -- the first convolution's operand and d4b's dz -- bit for bit, so a bf16x3 step launches no split pass for them."""
+    from fabric_amd._lib import BDN_F32, BDN_BF16X3
+    lib = _lib.load()
+    B, C, H, W, Cp = 3, 13, 20, 24, 16
+    a, b = dev(_rand((B, C, H, W), 91)), dev(_rand((B, C, H, W), 92))
+    x0 = torch.empty(2 * B, H, W, Cp, device='cuda')
+    _lib.call('bdn_pack_input', BDN_F32, a.data_ptr(), b.data_ptr(), x0.data_ptr(), B, C, H, W, Cp, st())
+    ref = torch.empty(2 * B, H, W, 2 * Cp, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', x0.data_ptr(), Cp, None, 0, IN_PLAIN, None, B, ref.data_ptr(), 2 * B, H, W, st())
+    got = torch.full_like(ref, float('nan'))
+    _lib.call('bdn_pack_input', BDN_BF16X3, a.data_ptr(), b.data_ptr(), got.data_ptr(), B, C, H, W, Cp, st())
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # head: dz of the layer in front of the classifier
+    B, H, W, C, ncls = 2, 33, 20, 64, 2
+    z_d = to_nhwc('fp32', _rand((B, C, H, W), 93))
+    bn_d = dev(bn_table(1, C, 94))
+    w_d, dl_d = dev(_rand((ncls, C), 95, 0.2)), dev(_rand((B, ncls, H, W), 96))
+    rows = lib.bdn_outc_bwd_rows(BDN_F32, B, H, W, C)
+    dw, db = torch.empty(ncls, C, device='cuda'), torch.empty(ncls, device='cuda')
+    part = torch.empty(rows, 2, C, device='cuda')
+    ows = torch.empty(lib.bdn_outc_bwd_workspace_bytes(BDN_F32, B, H, W, C, ncls) // 4, device='cuda')
+    _lib.call('bdn_outc_bwd', BDN_F32, dl_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), w_d.data_ptr(), None, dw.data_ptr(), db.data_ptr(),
+              part.data_ptr(), ows.data_ptr(), B, H, W, C, ncls, st())
+    sums = torch.empty(1, 2, C, device='cuda'); dg, dbt = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    _lib.call('bdn_bn_bwd_finalize', bn_d.data_ptr(), 1, C, part.data_ptr(), rows, 1, sums.data_ptr(), dg.data_ptr(), dbt.data_ptr(), None, st())
+    dz = torch.empty(B, H, W, C, device='cuda')
+    _lib.call('bdn_outc_bn_bwd_apply', BDN_F32, dl_d.data_ptr(), w_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), B, sums.data_ptr(),
+              dz.data_ptr(), B, H, W, C, ncls, st())
+    ref = torch.empty(B, H, W, 2 * C, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', dz.data_ptr(), C, None, 0, IN_PLAIN, None, B, ref.data_ptr(), B, H, W, st())
+    got = torch.full_like(ref, float('nan'))
+    _lib.call('bdn_outc_bn_bwd_apply', BDN_BF16X3, dl_d.data_ptr(), w_d.data_ptr(), z_d.data_ptr(), bn_d.data_ptr(), B, sums.data_ptr(),
+              got.data_ptr(), B, H, W, C, ncls, st())
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
 
 
 def test_split_outputs_of_the_bf16x3_producers_equal_split_pack():

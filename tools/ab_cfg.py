@@ -13,7 +13,7 @@ for a in sys.argv[1:]:
     kv = {}
     for item in filter(None, rest.split(',')):
         k, v = item.split('=')
-        kv[k] = int(v) if v.lstrip('-').isdigit() else (tuple(x for x in v.split('+') if x) if k == 'fold_bn_bwd' else v)
+        kv[k] = int(v) if v.lstrip('-').isdigit() else (tuple(x for x in v.split('+') if x) if (k == 'fold_bn_bwd' or '+' in v) else v)
     cfgs.append((name, kv))
 B = int(os.environ.get('AB_BATCH', '64'))
 x1 = torch.randn(B, 13, 128, 128, device='cuda'); x2 = torch.randn(B, 13, 128, 128, device='cuda')

@@ -47,6 +47,20 @@ for L in build_layers(13):
         fn = lambda: _lib.call('bdn_conv3x3', dt, sp.data_ptr(), cin, None, 0, 0, None, ipg, wt.data_ptr(), None, out.data_ptr(),
                                stats.data_ptr() if stats is not None else None, n, h, w, cout, st)
         t = timeit(fn)
+        if what == 'fwd' and cin % 64 == 0 and cin <= 512 and L.name[2] == 'b':
+            # the same stage from the float32 operand (BatchNorm+ReLU + split inside the staging, split operand left for the weight gradient)
+            # against the split pass + convolution it replaces
+            zf = torch.randn(n, h, w, cin, device='cuda')
+            bn = torch.rand(n // ipg, 4, cin, device='cuda') + 0.5
+            so = torch.empty(n, h, w, 2 * cin, device='cuda', dtype=torch.bfloat16)
+            t_sp = timeit(lambda: _lib.call('bdn_split_pack', zf.data_ptr(), cin, None, 0, 1, bn.data_ptr(), ipg, so.data_ptr(), n, h, w, st))
+            f_src = lambda keep: _lib.call('bdn_conv3x3_x3src', dt, zf.data_ptr(), cin, 1, bn.data_ptr(), ipg, wt.data_ptr(), None, out.data_ptr(),
+                                           stats.data_ptr(), so.data_ptr() if keep else None, n, h, w, cout, st)
+            t_src, t_src0 = timeit(lambda: f_src(True)), timeit(lambda: f_src(False))
+            a = tot.setdefault('fwd_b_split+conv', [0.0, 0.0]); a[0] += t + t_sp; a[1] += 2.0 * n * h * w * cout * 9 * cin * terms
+            a = tot.setdefault('fwd_b_x3src', [0.0, 0.0]); a[0] += t_src; a[1] += 2.0 * n * h * w * cout * 9 * cin * terms
+            print(f'{L.name} split_pack {t_sp * 1e6:7.1f} us + conv {t * 1e6:7.1f} us = {(t + t_sp) * 1e6:7.1f} us   x3src {t_src * 1e6:7.1f} us (without the by-product {t_src0 * 1e6:7.1f} us)')
+            del zf, bn, so
         fl = 2.0 * n * h * w * cout * 9 * cin * terms
         a = tot.setdefault(what, [0.0, 0.0]); a[0] += t; a[1] += fl
         print(f'{L.name} {what:7s} {n:4d}x{h:3d}x{w:3d} {cin:5d}->{cout:4d} {t * 1e6:8.1f} us {fl / t / 1e12:7.1f} TFLOP/s (executed bf16 MFMA work)')
