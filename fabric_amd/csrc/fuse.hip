@@ -425,7 +425,7 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dU, int ldU, T* __re
 // Tiled variant: a block owns 8x8 source pixels x UB channel units.  The 20x20 destination pixels that can reach them
 // ([2y-2, 2y+3] per axis, see above) are staged ONCE in LDS (one coalesced pass over dU, 1.56x halo overhead instead of the ~3x
 // re-reads of the per-pixel gather), then every thread gathers source pixels from LDS with the same separable weights.
-// UB = 8 (round 4; 64 channels = the whole 128-byte channel row of a pixel of the decoder's gradient slices, 56 KB of LDS) where C
+// UB = 8 (round 4; 64 channels = the whole 128-byte channel row of a pixel of the decoder's gradient slices, 50 KB of LDS) where C
 // allows it: with UB = 4 a block read 64-byte halves of 128-byte lines (level 1: 99 us for 168 MB).  UB = 4 (32 KB) otherwise.
 // Optionally (z_prev != NULL) the block also leaves the BatchNorm-backward partial sums of the layer whose relu(bn(z_prev)) was
 // upsampled -- sum g and sum g*z_prev over its 64 source pixels, g = (rounded) dsrc * [scale*z_prev + shift > 0] -- so that the
@@ -435,7 +435,9 @@ __global__ __launch_bounds__(UB == 8 ? 512 : 256) void upsample2x_bwd_tiled_kern
                                                                  int h, int w, int H, int W, int C, int tiles_x, int tiles_y,
                                                                  float sy, float sx, const T* __restrict__ z_prev, const float* __restrict__ bn_prev,
                                                                  float* __restrict__ bs_partial) {
-    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, PSTR = UB * 16 + 16, NT = 64 * UB;      // one thread per (source pixel, unit)
+    // pixel stride WITHOUT padding (round 6): 51.2 KB instead of 57.6 KB per block = three blocks per CU instead of two; the kernel is bound by the
+    // bytes its blocks keep in flight, not by the two-way bank conflicts of the gather (alone at B = 64: 134.7 -> 112 us, 2.8 -> 3.35 TB/s)
+    constexpr int EPU = ET<T>::EPU, TS = 8, R = 2 * TS + 4, PSTR = UB * 16, NT = 64 * UB;      // one thread per (source pixel, unit)
     __shared__ __attribute__((aligned(16))) unsigned char sm[R * R * PSTR];
     const int tid = threadIdx.x;
     // neighbouring tiles share 4 of their 20 window rows / columns: consecutive tiles stay on one XCD so that the overlap is an L2 hit
