@@ -228,6 +228,44 @@ def pmc_family_traffic(names, per_step_launches, precision):
                           'launch-weighted mean over the family\'s instantiations'}
 
 
+def leg_profile(leg, conv_launches, flop_per_unit_fwd, note):
+    """rocprof evidence of a leg that is NOT the bf16 training loop (tools/profile_legs.sh: profiles/<tag>_<leg>_kstats.csv from rocprofv3
+    --kernel-trace --stats, <tag>_<leg>_pmc.json from separate --pmc passes): the conv3x3_kernel<*> family's launch-weighted average
+    duration and HBM bytes per launch, and the MFMA fraction they give for `conv_launches` launches doing `flop_per_unit_fwd` FLOP -- so a
+    reader can recompute the leg's fraction from tracked files.  None when no such file is committed."""
+    ks = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{leg}_kstats.csv')))
+    if not ks:
+        return None
+    calls = tot = 0.0
+    inst = {}
+    for r in csv.DictReader(open(ks[-1])):
+        if r['Name'].startswith('void conv3x3_kernel<'):
+            calls += float(r['Calls']); tot += float(r['TotalDurationNs'])
+            inst[r['Name'].replace('unsigned short', 'bf16').replace('void ', '').replace('(ConvArgs)', '')] = \
+                {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3}
+    if not calls:
+        return None
+    avg = tot / calls / 1e3
+    out = {'kernel': 'conv3x3_kernel<*>', 'rocprof_source': os.path.relpath(ks[-1], ROOT), 'rocprof_avg_launch_us': avg, 'rocprof_launches': int(calls),
+           'instantiations': inst, 'note': note}
+    if conv_launches and flop_per_unit_fwd:
+        out['launches_per_unit'] = conv_launches
+        out['achieved'] = flop_per_unit_fwd / (avg * 1e-6 * conv_launches) / 1e12
+        out['peak'] = MFMA_BF16_PEAK / 1e12
+        out['unit'] = 'TFLOP/s'
+        out['frac'] = out['achieved'] / out['peak']
+    pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{leg}_pmc.json')))
+    if pm:
+        rd = wr = n = 0.0
+        for k, v in json.load(open(pm[-1])).items():
+            if k.startswith('conv3x3_kernel<') or k.startswith('void conv3x3_kernel<'):
+                n += v['launches']; rd += v['fetch_bytes_per_launch_corrected'] * v['launches']; wr += v['write_bytes_per_launch'] * v['launches']
+        if n:
+            out['traffic'] = {'unit': 'bytes/launch', 'hbm_read': rd / n, 'hbm_write': wr / n, 'source': os.path.relpath(pm[-1], ROOT),
+                              'correction': 'FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported; separate --pmc passes; launch-weighted over the family'}
+    return out
+
+
 def mfma_ceiling():
     """tools/probe_power_wall (built by __graft_entry__.build()): a bare v_mfma_f32_32x32x16_bf16 loop on every CU with all-zero and with
     N(0,1) bf16 operands.  The chip clocks to its power budget, so the rate on random data -- not the data-sheet 2.5 PFLOP/s -- is what
@@ -922,6 +960,11 @@ def main():
             del ts, model, eng, x1, x2, lbl
             torch.cuda.empty_cache()
             out['parity_setting'] = parity_leg(dev, B, C, S)
+            # (the profiled command is `bench.py --precision bf16x3`: three-term backward; algorithmic FLOP of the 35 forward + data-gradient launches)
+            out['parity_setting']['bf16x3']['roofline'] = leg_profile(
+                'x3', 35, (FLOP_PER_PAIR_FWD + FLOP_PER_PAIR_FWD - 0.491e9) * 64,
+                'bf16x3 step at B = 64: ALGORITHMIC conv FLOP (one product per multiply-add; the kernels execute three bf16 MFMAs per product) over '
+                'the family\'s profiled time, against the bf16 dense peak')
             for key, leg in (('val_f1', val_f1_leg), ('conv3d', conv3d_leg)):
                 try:
                     out[key] = leg(dev)
@@ -929,6 +972,13 @@ def main():
                     out[key] = {'error': f'{type(e).__name__}: {e}'}
                 torch.cuda.empty_cache()
             out['scene'] = scene_leg(dev, size=args.scene_size)
+            lp = leg_profile('scene', 18, FLOP_PER_PAIR_FWD * 256,
+                             'eval-shaped forward of one 256-tile batch: 18 convolution launches (10 encoder incl. 5 date-paired, 8 decoder) for 256 x 23.14 GFLOP')
+            if lp is not None and isinstance(out['scene'].get('roofline'), dict):
+                out['scene']['roofline'].update({'rocprof_' + k if not k.startswith('rocprof_') else k: v for k, v in lp.items()})
+            if isinstance(out.get('conv3d'), dict) and 'error' not in out['conv3d']:
+                out['conv3d']['rocprof'] = leg_profile('conv3d', 0, 0, 'tools/bench_conv3d_block.py under rocprofv3: per-instantiation average launch times (CKB = 32: the '
+                                                       '13 -> 64 layers, 128: the 64 -> 64 layers; D3 = true marks the 3x3x3 walk); the 2 x 5 and 16 x 5 batches share an instantiation')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         json_out.write(json.dumps(out) + '\n')
