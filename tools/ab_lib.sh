@@ -1,6 +1,6 @@
 #!/bin/bash
 # Step time of two or more builds of the library on ONE box, alternating:  tools/ab_lib.sh [--precision bf16x3] name1 name2 ...
-# (names of fabric_amd/csrc/variants/lib_<name>.so, e.g. built by tools/archive/build_variants.sh)
+# (names of fabric_amd/csrc/variants/lib_<name>.so, e.g. built by tools/build_lib_variant.sh)
 extra=""
 if [ "$1" == "--precision" ]; then extra="--precision $2"; shift 2; fi
 for rep in 1 2; do
