@@ -90,6 +90,7 @@ SIGNATURES = {
     'bdn_focal': (_i, [_vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_ingest_band': (_i, [_i, _vp, _i, _i, _f, _f, _vp, _i, _i, _vp]),
     'bdn_gather_tiles': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'bdn_upload_band': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_argmax': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_argmax_stitch': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'bdn_sgd_step': (_i, [_vp, _vp, _f, _f, _sz, _vp]),

@@ -5,6 +5,19 @@
 
 static inline unsigned grid_for(size_t n, int block = 256) { return (unsigned)((n + block - 1) / block); }
 
+// ============================================================ band upload
+// One row band of ALL band planes of a host scene in ONE copy: [C] planes of H x W float32, rows [r0, r1) of each -- a 2-D copy of C "rows" of
+// (r1 - r0) * W * 4 bytes at pitch H * W * 4 (what train.py:190-193 does per batch with .to(device), here per band of the resident scene).
+// The round-5 feeder issued one copy per plane (26 per band for both dates); boxes whose DMA engines pay more per copy sustained 37 of 57 GB/s.
+extern "C" int bdn_upload_band(float* dst_planes, const float* src_planes_host, int C, int H, int W, int r0, int r1, void* stream) {
+    if (!dst_planes || !src_planes_host) BDN_FAIL(BDN_E_ARG, "upload_band: null pointer");
+    if (C <= 0 || H <= 0 || W <= 0 || r0 < 0 || r1 <= r0 || r1 > H) BDN_FAIL(BDN_E_SHAPE, "upload_band: bad C=%d H=%d W=%d rows [%d, %d)", C, H, W, r0, r1);
+    const size_t pitch = (size_t)H * W * sizeof(float), off = (size_t)r0 * W, width = (size_t)(r1 - r0) * W * sizeof(float);
+    const hipError_t e = hipMemcpy2DAsync(dst_planes + off, pitch, src_planes_host + off, pitch, width, (size_t)C, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) BDN_FAIL(BDN_E_HIP, "upload_band: hipMemcpy2DAsync: %s", hipGetErrorString(e));
+    return BDN_OK;
+}
+
 // ============================================================ gather_tiles
 // reference: utils/inference.py:134-184 (_get_patches) + :61-66 (NHWC->NCHW transpose) + train.py:190-193
 // (batch slice, host->device).  scene_d*: [C][H][W] f32 band planes.  origins: int32 [n][2] = (y0, x0).

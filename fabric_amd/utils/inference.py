@@ -21,6 +21,8 @@ from os import path
 import numpy as np
 import torch
 
+from .. import _lib
+
 
 
 def get_path(path_list):
@@ -247,6 +249,10 @@ class _SceneFeeder:
         self.d2.record_stream(self.cur)
         self._issue(self.LOOKAHEAD)
 
+    # pinned sources: True = one hipMemcpy2DAsync per band and date (bdn_upload_band) instead of one copy per plane (26 -> 2 copies per band).
+    # Measured on a box that sustains 53 GB/s either way: 0.196 s per-plane, 0.200 s 2-D for the 10 000^2 scene -- off; kept as the A/B switch
+    # for boxes where the per-plane form sustains 37 of 57 GB/s (tools/bench_scene_hostfed.py, BAND2D=1)
+    band_copy_2d = False
     LOOKAHEAD = 4        # bands enqueued beyond the one a batch waits for: the copy stream never runs dry, the host never runs far ahead
 
     def _issue(self, upto):
@@ -266,9 +272,12 @@ class _SceneFeeder:
             evs = []
             for d, (dst, cs) in enumerate(((self.d1, self.copy), (self.d2, self.copy2))):
                 with torch.cuda.stream(cs):
-                    for c in range(C):                   # one contiguous [rows, W] block per plane
-                        src = self.src[d][c, r0:r1] if self.pinned else self.stage[d][k % 2][c, :r1 - r0]
-                        dst[c, r0:r1].copy_(src, non_blocking=True)
+                    if self.pinned and self.band_copy_2d:        # all planes' rows of the band in ONE 2-D copy (26 copies per band -> 2)
+                        _lib.call('bdn_upload_band', dst.data_ptr(), self.src[d].data_ptr(), C, self.H, self.src[d].shape[2], r0, r1, cs.cuda_stream)
+                    else:
+                        for c in range(C):               # one contiguous [rows, W] block per plane
+                            src = self.src[d][c, r0:r1] if self.pinned else self.stage[d][k % 2][c, :r1 - r0]
+                            dst[c, r0:r1].copy_(src, non_blocking=True)
                     e_ = torch.cuda.Event()
                     e_.record(cs)
                     evs.append(e_)
