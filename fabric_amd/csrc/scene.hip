@@ -113,9 +113,8 @@ extern "C" int bdn_ingest_band(int src_is_f32, const void* src, int hs, int ws, 
 // a pixel belongs to the far-edge band(s) it lies in (y >= H-p, x >= W-p) and only a tile anchored on exactly
 // those bands writes it, so tiles of one launch never race with different values.
 __global__ void argmax_stitch_kernel(const float* __restrict__ logits, const int* __restrict__ origins,
-                                     unsigned char* __restrict__ out, int n, int ncls, int p, int H, int W) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t pp = (size_t)p * p;
+                                     unsigned char* __restrict__ out, int n, int ncls, int p, int H, int W, size_t pp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // pp: pixels per image (p * p for tiles; H * W for the plain argmax of [n,ncls,H,W])
     if (i >= (size_t)n * pp) return;
     const int tile = i / pp; const int rem = i % pp;
     const float* l = logits + (size_t)tile * ncls * pp + rem;
@@ -134,9 +133,9 @@ __global__ void argmax_stitch_kernel(const float* __restrict__ logits, const int
 
 extern "C" int bdn_argmax(const float* logits, uint8_t* out, int n, int ncls, int H, int W, void* stream) {
     if (!logits || !out) BDN_FAIL(BDN_E_ARG, "argmax: null pointer");
-    if (n <= 0 || ncls <= 0 || ncls > 256 || H <= 0 || W <= 0 || H != W) BDN_FAIL(BDN_E_SHAPE, "argmax: bad shape (square patches, <= 256 classes)");
+    if (n <= 0 || ncls <= 0 || ncls > 256 || H <= 0 || W <= 0) BDN_FAIL(BDN_E_SHAPE, "argmax: bad shape (<= 256 classes)");
     hipLaunchKernelGGL(argmax_stitch_kernel, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream,
-                       logits, (const int*)nullptr, out, n, ncls, H, H, W);
+                       logits, (const int*)nullptr, out, n, ncls, H, H, W, (size_t)H * W);
     BDN_CHECK_LAUNCH("argmax");
     return BDN_OK;
 }
@@ -146,7 +145,7 @@ extern "C" int bdn_argmax_stitch(const float* logits, const int32_t* origins, ui
     if (!logits || !origins || !mask) BDN_FAIL(BDN_E_ARG, "argmax_stitch: null pointer");
     if (n_tiles <= 0 || ncls <= 0 || ncls > 256 || p <= 0 || H < p || W < p) BDN_FAIL(BDN_E_SHAPE, "argmax_stitch: bad shape");
     hipLaunchKernelGGL(argmax_stitch_kernel, dim3(grid_for((size_t)n_tiles * p * p)), dim3(256), 0, (hipStream_t)stream,
-                       logits, origins, mask, n_tiles, ncls, p, H, W);
+                       logits, origins, mask, n_tiles, ncls, p, H, W, (size_t)p * p);
     BDN_CHECK_LAUNCH("argmax_stitch");
     return BDN_OK;
 }

@@ -249,10 +249,11 @@ class _SceneFeeder:
         self.d2.record_stream(self.cur)
         self._issue(self.LOOKAHEAD)
 
-    # pinned sources: True = one hipMemcpy2DAsync per band and date (bdn_upload_band) instead of one copy per plane (26 -> 2 copies per band).
-    # Measured on a box that sustains 53 GB/s either way: 0.196 s per-plane, 0.200 s 2-D for the 10 000^2 scene -- off; kept as the A/B switch
-    # for boxes where the per-plane form sustains 37 of 57 GB/s (tools/bench_scene_hostfed.py, BAND2D=1)
-    band_copy_2d = False
+    # pinned sources: one hipMemcpy2DAsync per band and date (bdn_upload_band) instead of one copy per plane (26 -> 2 copies per band).  Boxes come in two
+    # kinds (same plain-copy rate, 57.6 GB/s): on one the per-plane form sustains 53 GB/s beside the forward and the 2-D form 52 (0.196 vs 0.200 s for
+    # the 10 000^2 scene), on the other the per-plane form sustains 37.7 GB/s (0.276 s, 0.66 of max(compute, PCIe) -- the driver's box of rounds 5) and
+    # the 2-D form 52.7 (0.197 s, 0.91).  False = the per-plane form (tools/bench_scene_hostfed.py, BAND2D=0)
+    band_copy_2d = True
     LOOKAHEAD = 4        # bands enqueued beyond the one a batch waits for: the copy stream never runs dry, the host never runs far ahead
 
     def _issue(self, upto):

@@ -415,8 +415,7 @@ int bdn_gather_tiles(int dtype, const float* scene_d1, const float* scene_d2, co
 /* Rows [r0, r1) of all C band planes of a HOST scene [C][H][W] f32 (pinned for an asynchronous copy) into the resident device planes, as one
  * 2-D copy on `stream` (the host -> device staging of train.py:190-193 / utils/dataloaders.py:86-101, per row band of the scene instead of per batch). */
 int bdn_upload_band(float* dst_planes, const float* src_planes_host, int C, int H, int W, int r0, int r1, void* stream);
-/* `_, cd_preds = torch.max(preds, 1)` (train.py:199; first maximum wins): logits [n][ncls][H][W] f32 -> uint8 [n][H][W]
- * (square patches only). */
+/* `_, cd_preds = torch.max(preds, 1)` (train.py:199; first maximum wins): logits [n][ncls][H][W] f32 -> uint8 [n][H][W]. */
 int bdn_argmax(const float* logits, uint8_t* out, int n, int ncls, int H, int W, void* stream);
 /* argmax + _get_bands (utils/inference.py:187-236): class index of every tile pixel written to mask [H][W] uint8 at
  * the tile origin; far-edge tiles own the far-edge bands exactly as the reference's paste order leaves them. */

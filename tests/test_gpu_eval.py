@@ -249,7 +249,7 @@ def _load(golden_dir, name):
     return g, c, torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()
 
 
-@pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90', 'g2_c13_b2_s128'])
+@pytest.mark.parametrize('name', ['g1_c3_b4_s32', 'g4_c13_b2_s90', 'g2_c13_b2_s128', 'g8_c13_b3_h40_w72'])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_eval_schedule_matches_the_training_kernel_eval_path(golden_dir, name, prec):
     """model.eval() logits of the eval-shaped schedule against the round 1-5 path (training kernels on a running-statistics table) and,
@@ -283,6 +283,30 @@ def test_eval_schedule_matches_the_training_kernel_eval_path(golden_dir, name, p
     assert torch.equal(cd.cpu(), (new[:, 1] > new[:, 0]).to(torch.uint8))
     sd = model.state_dict()
     assert all(int(sd[k]) == 0 for k in sd if 'num_batches_tracked' in k)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_eval_schedule_with_a_wider_head(prec):
+    """n_classes = 3 (outconv, models/unet_parts.py:83-90, wider than the fused classifier epilogue takes): the eval-shaped schedule stores the last
+    activation and runs the stand-alone classifier on it; logits against the training-kernel eval path, class map = first maximum (train.py:199)."""
+    torch.manual_seed(5)
+    model = BiDateNet(3, 3, precision=prec).cuda()
+    x1, x2 = torch.randn(3, 3, 40, 56, device='cuda'), torch.randn(3, 3, 40, 56, device='cuda')
+    model.train()
+    with torch.no_grad():
+        for _ in range(2):
+            model(x1, x2)                       # running statistics away from their initial values
+    model.eval()
+    eng = model.engine()
+    with torch.no_grad():
+        new = model(x1, x2).cpu()
+        cd, _ = eng.forward(x1, x2, {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}, training=False, class_map=True)
+        eng.eval_fused = False
+        old = model(x1, x2).cpu()
+        eng.eval_fused = True
+    assert new.shape == (3, 3, 40, 56)
+    assert (new - old).abs().max().item() <= {'fp32': 2e-5, 'bf16': 3e-2}[prec] * old.abs().max().item()
+    assert torch.equal(cd.cpu(), new.argmax(1).to(torch.uint8))
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
