@@ -973,7 +973,9 @@ def main():
                 torch.cuda.empty_cache()
             out['scene'] = scene_leg(dev, size=args.scene_size)
             lp = leg_profile('scene', 18, FLOP_PER_PAIR_FWD * 256,
-                             'eval-shaped forward of one 256-tile batch: 18 convolution launches (10 encoder incl. 5 date-paired, 8 decoder) for 256 x 23.14 GFLOP')
+                             'eval-shaped forward of one 256-tile batch: 18 convolution launches (10 encoder incl. 5 date-paired, 8 decoder) for 256 x 23.14 GFLOP; '
+                             'profiled on ONE lane (tools/bench_scene.py --one-lane: clean per-kernel durations; the timed leg above runs two lanes, whose '
+                             'kernels overlap), so rocprof_frac is the convolutions\' own MFMA fraction, without gather / upsample launches and lane overlap')
             if lp is not None and isinstance(out['scene'].get('roofline'), dict):
                 out['scene']['roofline'].update({'rocprof_' + k if not k.startswith('rocprof_') else k: v for k, v in lp.items()})
             if isinstance(out.get('conv3d'), dict) and 'error' not in out['conv3d']:
