@@ -79,6 +79,7 @@ SIGNATURES = {
     'bdn_tversky': (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bb_variant': (C.c_char_p, [_i, _i, _i, _i, _i]),
+    'bdn_conv3x3_x3src_variant': (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     'bdn_conv3x3_dgrad_bs': (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'bdn_conv3x3_dgrad_bb': (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'bdn_bn_bwd_scratch_bytes': (_sz, [_i, _i]),

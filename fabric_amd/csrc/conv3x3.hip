@@ -1157,6 +1157,16 @@ extern "C" int bdn_conv3x3_x3src(int dtype, const float* in, int C0, int in_mode
     return dtype == BDN_BF16X3 ? dispatch_conv_x3f<3, true>(a, g, st) : dispatch_conv_x3f<2, true>(a, g, st);
 }
 
+extern "C" const char* bdn_conv3x3_x3src_variant(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group) {
+    g_conv_variant[0] = 0;
+    g_conv_query = true;
+    const float* dummy = reinterpret_cast<const float*>(16);      // never dereferenced: nothing is launched in query mode
+    const int rc = bdn_conv3x3_x3src(dtype, dummy, C0, BDN_IN_PLAIN, nullptr, imgs_per_group, dummy, nullptr, const_cast<float*>(dummy), nullptr, nullptr,
+                                     N, H, W, Cout, nullptr);
+    g_conv_query = false;
+    return rc == BDN_OK ? g_conv_variant : "";
+}
+
 extern "C" int bdn_conv3x3_dgrad_bs(int dtype, const void* dz, int C0, const void* w_dgrad, void* dA,
                                     const void* z_prev, const float* bn_prev, int imgs_per_group, float* bs_partial,
                                     int N, int H, int W, int Cout, void* stream) {

@@ -290,8 +290,13 @@ class BiDateEngine:
 
     def _timed_conv(self, n, h, w, c0, c1, cout, ipg, *args, fn='bdn_conv3x3', bb=False):
         name = None
-        if self.prof is not None:                   # BatchNorm-backward-on-load launches have their own dispatcher: ask it
-            name = _lib.load().bdn_conv3x3_dgrad_bb_variant(n, h, w, cout, ipg).decode() if bb else self.conv_kernel_name(n, h, w, c0, c1, cout, ipg)
+        if self.prof is not None:                   # BatchNorm-backward-on-load and float32-source launches have their own dispatchers: ask them
+            if bb:
+                name = _lib.load().bdn_conv3x3_dgrad_bb_variant(n, h, w, cout, ipg).decode()
+            elif fn == 'bdn_conv3x3_x3src':
+                name = _lib.load().bdn_conv3x3_x3src_variant(args[0], n, h, w, c0, cout, ipg).decode()
+            else:
+                name = self.conv_kernel_name(n, h, w, c0, c1, cout, ipg)
         if self.prof is None or (self.prof_filter is not None and name not in self.prof_filter):
             call(fn, *args)
             return

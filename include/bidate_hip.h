@@ -105,6 +105,8 @@ const char* bdn_conv3x3_variant(int dtype, int N, int H, int W, int C0, int C1, 
 int bdn_conv3x3_x3src(int dtype, const float* in, int C0, int in_mode, const float* in_bn, int imgs_per_group,
                       const void* w, const float* bias, float* out, float* stats_partial, void* split_out,
                       int N, int H, int W, int Cout, void* stream);
+/* Name of the kernel instantiation bdn_conv3x3_x3src runs for a shape (as bdn_conv3x3_variant); "" for an unsupported shape. */
+const char* bdn_conv3x3_x3src_variant(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group);
 
 /* Data gradient of nn.Conv2d(ci,co,3,padding=1) (autograd of models/unet_parts.py:13,16) with the BatchNorm-backward
  * statistics of the PRODUCING layer fused into the epilogue: dz [N,H,W,C0] x rotated filter image w_dgrad ->

@@ -63,6 +63,8 @@ def test_argument_validation_needs_no_gpu():
     assert lib.bdn_conv3d_num_mtiles(8, 5, 128, 128) == 8 * 5 * 16 * 8
     assert lib.bdn_conv3x3_variant(BDN_BF16, 128, 64, 64, 128, 0, 128, 64) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,bf16,false,false,false,0,false>'
     assert lib.bdn_conv3x3_variant(BDN_BF16X3, 128, 64, 64, 128, 0, 128, 64).endswith(b'float,false,false,false,3,false>')
+    assert lib.bdn_conv3x3_x3src_variant(BDN_BF16X3, 128, 64, 64, 128, 128, 64) == b'conv3x3_kernel<bf16,128,8,16,1,128,1,4,false,float,false,false,false,3,true>'
+    assert lib.bdn_conv3x3_x3src_variant(BDN_BF16X3, 128, 64, 64, 1024, 128, 64) == b''        # operands beyond the staging table
     for name, args, msg in (
             ('bdn_conv3d', (BDN_BF16, None, 64, 0, None, 1, None, None, None, None, 1, 1, 8, 8, 64, None), 'null pointer'),
             ('bdn_conv3d', (7, 1, 64, 0, None, 1, 1, None, 1, None, 1, 1, 8, 8, 64, None), 'bad dtype'),
