@@ -154,7 +154,8 @@ class Workspace:
         self._chain2 = None        # (stats, bnws) of the second forward chain, allocated when the two-chain forward first runs
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
-        self.n_wg1 = lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, 256)) // 4
+        self.n_wg1 = max(lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, blocks)) // 4
+                         for blocks in (0, 256, 512))      # (0 / 512: the plain GEMM when it runs on the chain's stream, engine.last_wgrad_on_chain)
         self._bwd = None
         self._split = {}
         self._outc_ws = None
@@ -272,6 +273,9 @@ class BiDateEngine:
         # queue.  True = every eligible layer (no split pass left in a step), a tuple of layer names = only those (eval forwards then take it
         # for operands of <= 128 channels), False = none (rounds 3-5; the checker of the fused form in tests)
         self.x3_src_f32 = True
+        # the first convolution's weight gradient (the last GEMM of a backward pass, where the bf16 path runs its fused first-layer kernel on the chain's
+        # stream) is launched on the chain's stream instead of behind the previous layer's GEMM on the second queue (fp32 / bf16x3 settings)
+        self.last_wgrad_on_chain = True
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
@@ -802,7 +806,7 @@ class BiDateEngine:
                 return dz, out, self.mtiles(n, hk, wk, L.cout, L.cin, ipg) // G
             return dz, out
 
-        def wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, stp):
+        def wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, stp, part_key='p'):
             """The weight-gradient GEMM and its reduction; with profiling on, the GEMM alone sits between two events
             recorded on the stream it is launched on."""
             lib = _lib.load()
@@ -814,13 +818,13 @@ class BiDateEngine:
                 flg = wg_flags(3, 0, self.wgrad_blocks)
                 xdt = BDN_BF16X2 if self.x3_bwd_terms == 2 else BDN_BF16X3
                 nb = lib.bdn_wgrad_workspace_bytes_ex(xdt, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, flg)
-                part = ws.split_buf('p', nb // 2)
+                part = ws.split_buf(part_key, nb // 2)        # ('p1': the one GEMM that runs on the chain's stream beside the queue's own)
                 call('bdn_conv3x3_wgrad_ex', xdt, ptr(sd), L.cout, ptr(sw), c0 + c1, None, 0, IN_PLAIN, None, ipg,
                      ptr(part), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk, flg, stp)
                 return
             wk_, blk_ = self.wgrad_kernel, self.wgrad_blocks
             args = (self.dt, ptr(dz), L.cout, ptr(in0), c0, ptr(in1), c1, mode, ptr(in_bn), ipg,
-                    ptr(sc['wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
+                    ptr(sc['wg1' if part_key == 'p1' else 'wg']), ptr(grads[f'{L.conv}.weight']), L.cin_real, n, hk, wk)
             name = None
             if self.prof is not None:
                 v = lib.bdn_conv3x3_wgrad_variant(self.dt, n, hk, wk, L.cout, c0, c1, ipg, mode, wg_flags(3, wk_, blk_))
@@ -870,13 +874,24 @@ class BiDateEngine:
             call('bdn_split_pack', ptr(dz), L.cout, None, 0, IN_PLAIN, None, ipg, ptr(sp), n, hk, wk, st)
             return sp
 
-        def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg):
+        def wgrad(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, on_main=False):
             if self.x3 and dz is not None:
                 split_dz(L, dz, n, ipg)              # on the chain's stream, before the hand-off below (bn_bwd already left the split otherwise)
             if self._diag_skip_wgrad:                # tools/ab_step.py diagnostic only: how long is the dz chain alone?
                 return
             hk, wk = ws.dims[L.level - 1]
             keys = [f'{L.bn}.weight', f'{L.bn}.bias', f'{L.conv}.weight', f'{L.conv}.bias']
+            if on_main and side is not None:
+                # the LAST weight gradient of the pass (the first convolution's) on the chain's own stream: nothing of the chain is left to
+                # run and the second queue is still busy with the layer before it -- the two GEMMs run side by side instead of one behind
+                # the other (bf16x3: 0.36 ms behind a 1.3 ms GEMM at the end of the step).  The chain then joins the second queue: the
+                # bucket this ready() may release holds gradients whose GEMMs are still queued there.
+                wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, st, part_key='p1')
+                if zero_bias_grads:
+                    grads[f'{L.conv}.bias'].zero_()
+                handoff(side, main)
+                ready(keys)
+                return
             if side is None:
                 wgrad_call(L, dz, in0, c0, in1, c1, mode, in_bn, n, ipg, hk, wk, st)
                 if zero_bias_grads:                  # feeds a BatchNorm: gradient is identically zero
@@ -1028,7 +1043,7 @@ class BiDateEngine:
                 dP = dP_new
                 continue
             dza = bn_bwd(La, ptr(dAa), La.cout, 2 * B, B, fused_rows=rows)
-            wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B)
+            wgrad(La, dza, src, La.cin, None, 0, IN_PLAIN, None, 2 * B, B, on_main=(k == 1 and self.last_wgrad_on_chain))
             keep += [dAb, dzb, dAa, dza, dP]
             dP = dgrad(La, dza, 2 * B, B) if k > 1 else None
         if side is not None:

@@ -14,7 +14,7 @@ mkdir -p gpurun_out
 for leg in $legs; do
     case $leg in
         x3)     cmd="python bench.py --precision bf16x3 --steps 10 --warmup 4 --windows 1 --no-cpu-baseline --no-extras"
-                pmc="python bench.py --precision bf16x3 --steps 3 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-extras"; units=5; marker=pack_input_kernel ;;
+                pmc="python bench.py --precision bf16x3 --steps 3 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-extras"; units=5; marker=pack_input ;;
         scene)  cmd="python tools/bench_scene.py --size 10000 --batch 256 --reps 2 --one-lane"      # one lane: per-kernel durations without the other lane's kernels beside them
                 pmc="python tools/bench_scene.py --size 4096 --batch 256 --reps 1"; units=8; marker=gather_tiles_kernel ;;
         conv3d) cmd="python tools/bench_conv3d_block.py"
