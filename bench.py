@@ -341,14 +341,17 @@ def step_classes(ts, x1, x2, lbl, B, dev):
 
 # ---------------------------------------------------------------------------------------------- extra legs (rank 0, N = 1)
 def _time_steps(ts, x1, x2, lbl, warm, n):
-    for _ in range(warm):
-        ts.step(x1, x2, lbl)
+    # on the step's own stream, as the headline loop and fabric_amd/train.py run it (no cross-stream joins around every step)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        ts.step(x1, x2, lbl)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    with torch.cuda.stream(ts.stream()):
+        for _ in range(warm):
+            ts.step(x1, x2, lbl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ts.step(x1, x2, lbl)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
 
 
 def host_fed_leg(ts, dev, B, C, S, steps, warmup, x1, x2, lbl):

@@ -697,6 +697,193 @@ __global__ __launch_bounds__(256, 2) void wgrad_first_kernel(WgFirstArgs a) {
     }
 }
 
+// ---- bf16x3 / bf16x2 form of the first layer's weight gradient (round 6).  float32 dA and z; the staging forms dz in float32 with
+// bn_bwd_apply_kernel<float>'s expression, splits it into bf16 hi + lo (bdn_split_pack's arithmetic) into TWO LDS tiles, the input patch comes
+// split already ([pixel][hi 16 | lo 16] bf16: what bdn_pack_input(BDN_BF16X3) stores), and every (k-step, tap pair) issues
+//     acc += dz_hi x_hi;  acc += dz_hi x_lo;  [acc += dz_lo x_hi]        (TERMS = 3; 2 = dz rounded to bf16: BDN_BF16X2)
+// into the SAME accumulator -- no doubled operands, no quadrant tile, no combine pass; the split dz of the layer is never written, the
+// bn_bwd_apply_split pass over dA and z (1.6 GB at B = 64) and the generic k-split GEMM behind it do not run.
+struct WgFirstX3Args {
+    const float* dA; int ldA; const float* z; const float* bn; const float* sums; const bf16s* xs;       // xs [N,H,W,32]: hi(16) | lo(16)
+    float* partial;                // [S][9][64][16]
+    int N, H, W, imgs_per_group;
+    int tiles_y, tiles_x, n_mtiles, S, per_split;
+    float invM;
+};
+struct WgFX {
+    static constexpr int PATCH_BYTES = WgF::PATCH_BYTES, DZ_BYTES = WgF::DZ_BYTES;
+    static constexpr int MAIN_BYTES = 2 * PATCH_BYTES + 2 * DZ_BYTES;
+    static constexpr int SMEM = MAIN_BYTES > WgF::RED_BYTES ? MAIN_BYTES : WgF::RED_BYTES;
+};
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void wgrad_first_x3_kernel(WgFirstX3Args a) {
+    using TL = WgF::TL;
+    constexpr int C = 64, PSTR = WgF::PSTR, DSTR = WgF::DSTR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch_h = smem;
+    unsigned char* patch_l = smem + WgFX::PATCH_BYTES;
+    unsigned char* dzt_h = smem + 2 * WgFX::PATCH_BYTES;
+    unsigned char* dzt_l = dzt_h + WgFX::DZ_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, kpar = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int split = xcd_remap(blockIdx.x, gridDim.x);
+
+    const int c8 = (tid & 7) * 8;
+    uint4 gq[4][2], zq[4][2], ph[2], pl[2];
+    unsigned ok = 0;
+    int grp_next = 0, grp_cur = -1;
+    float mean[8], inv[8], sc[8], sh[8], k0[8], k1[8];
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+#define LOAD_CHUNK(q_)                                                                                   \
+    {                                                                                                   \
+        const int tx_ = (q_) % a.tiles_x, ty_ = ((q_) / a.tiles_x) % a.tiles_y, n_ = (q_) / (a.tiles_x * a.tiles_y); \
+        const int y0_ = ty_ * 8, x0_ = tx_ * 16;                                                        \
+        grp_next = n_ / a.imgs_per_group; ok = 0;                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
+            const int slot = (tid + i * 256) >> 3, y = y0_ + (slot >> 4), x = x0_ + (slot & 15);         \
+            const bool ok_ = y < a.H && x < a.W;                                                         \
+            const size_t pix = ((size_t)n_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);             \
+            gq[i][0] = *reinterpret_cast<const uint4*>(a.dA + pix * a.ldA + c8);                         \
+            gq[i][1] = *reinterpret_cast<const uint4*>(a.dA + pix * a.ldA + c8 + 4);                     \
+            zq[i][0] = *reinterpret_cast<const uint4*>(a.z + pix * C + c8);                              \
+            zq[i][1] = *reinterpret_cast<const uint4*>(a.z + pix * C + c8 + 4);                          \
+            ok |= (ok_ ? 1u : 0u) << i;                                                                  \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
+            const int u = tid + i * 256, pp = u >> 1, yy = pp / TL::PW, xx = pp % TL::PW;                \
+            const int y = y0_ + yy - 1, x = x0_ + xx - 1;                                                \
+            const bool ok_ = u < TL::NPIX * 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
+            const size_t pix = ((size_t)n_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);             \
+            ph[i] = *reinterpret_cast<const uint4*>(a.xs + pix * 32 + (u & 1) * 8);                      \
+            pl[i] = *reinterpret_cast<const uint4*>(a.xs + pix * 32 + 16 + (u & 1) * 8);                 \
+            ok |= (ok_ ? 1u : 0u) << (8 + i);                                                            \
+        }                                                                                               \
+    }
+#define STORE_CHUNK()                                                                                    \
+    {                                                                                                   \
+        if (grp_next != grp_cur) {                                                                      \
+            grp_cur = grp_next;                                                                         \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                              \
+                mean[e] = bn_row(a.bn, grp_cur, 0, C)[c8 + e]; inv[e] = bn_row(a.bn, grp_cur, 1, C)[c8 + e]; \
+                sc[e] = bn_row(a.bn, grp_cur, 2, C)[c8 + e]; sh[e] = bn_row(a.bn, grp_cur, 3, C)[c8 + e]; \
+                k0[e] = a.sums[((size_t)grp_cur * 2 + 0) * C + c8 + e] * a.invM;                         \
+                k1[e] = a.sums[((size_t)grp_cur * 2 + 1) * C + c8 + e] * a.invM;                         \
+            }                                                                                           \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
+            float fz[8], fg[8], o[8], hf[8], r[8];                                                      \
+            Unit<float>::unpack(zq[i][0], fz); Unit<float>::unpack(zq[i][1], fz + 4);                   \
+            Unit<float>::unpack(gq[i][0], fg); Unit<float>::unpack(gq[i][1], fg + 4);                   \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                              \
+                const float gm = fmaf(fz[e], sc[e], sh[e]) > 0.f ? fg[e] : 0.f;                          \
+                const float xhat = (fz[e] - mean[e]) * inv[e];                                          \
+                o[e] = sc[e] * (gm - k0[e] - xhat * k1[e]);                                             \
+                asm volatile("" : "+v"(o[e]));              /* the float32 dz, pinned: lo is the residual of the ROUNDED product (store_split4) */ \
+            }                                                                                           \
+            uint4 vh_ = Unit<bf16s>::pack(o);                                                            \
+            Unit<bf16s>::unpack(vh_, hf);                                                                \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) r[e] = o[e] - hf[e];                           \
+            uint4 vl_ = Unit<bf16s>::pack(r);                                                            \
+            const bool ok_ = (ok >> i) & 1u;                                                             \
+            vh_.x = ok_ ? vh_.x : 0u; vh_.y = ok_ ? vh_.y : 0u; vh_.z = ok_ ? vh_.z : 0u; vh_.w = ok_ ? vh_.w : 0u; \
+            vl_.x = ok_ ? vl_.x : 0u; vl_.y = ok_ ? vl_.y : 0u; vl_.z = ok_ ? vl_.z : 0u; vl_.w = ok_ ? vl_.w : 0u; \
+            const unsigned o_ = ((tid + i * 256) >> 3) * DSTR + (tid & 7) * 16;                          \
+            *reinterpret_cast<uint4*>(dzt_h + o_) = vh_;                                                 \
+            if (TERMS == 3) *reinterpret_cast<uint4*>(dzt_l + o_) = vl_;                                 \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
+            const int u = tid + i * 256;                                                                 \
+            uint4 vh_ = ph[i], vl_ = pl[i];                                                              \
+            const bool ok_ = (ok >> (8 + i)) & 1u;                                                       \
+            vh_.x = ok_ ? vh_.x : 0u; vh_.y = ok_ ? vh_.y : 0u; vh_.z = ok_ ? vh_.z : 0u; vh_.w = ok_ ? vh_.w : 0u; \
+            vl_.x = ok_ ? vl_.x : 0u; vl_.y = ok_ ? vl_.y : 0u; vl_.z = ok_ ? vl_.z : 0u; vl_.w = ok_ ? vl_.w : 0u; \
+            if (u < TL::NPIX * 2) {                                                                     \
+                *reinterpret_cast<uint4*>(patch_h + (u >> 1) * PSTR + (u & 1) * 16) = vh_;               \
+                *reinterpret_cast<uint4*>(patch_l + (u >> 1) * PSTR + (u & 1) * 16) = vl_;               \
+            }                                                                                           \
+        }                                                                                               \
+    }
+
+    const int kpix = (lane & 15) >> 2, upper = (lane >> 4) & 1;
+    const unsigned a_off = (half * 8 + kpix) * DSTR + wm * 64 + (16 * upper + 4 * (lane & 3)) * 2;
+    const unsigned b_off = (lane & 3) * 8;
+    unsigned tapoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int tap = min(2 * j + upper, 8);
+        tapoff[j] = ((tap / 3) * TL::PW + tap % 3) * PSTR + b_off;
+    }
+
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    if (q_begin < q_end) LOAD_CHUNK(q_begin)
+    for (int q = q_begin; q < q_end; q++) {
+        __syncthreads();
+        STORE_CHUNK()
+        __syncthreads();
+        if (q + 1 < q_end) LOAD_CHUNK(q + 1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kk = 2 * ks + kpar;
+            const unsigned ao = a_off + kk * 16 * DSTR;
+            const uint4 afh = tr_pair(dzt_h + ao, dzt_h + ao + 4 * DSTR);
+            uint4 afl = afh;
+            if (TERMS == 3) afl = tr_pair(dzt_l + ao, dzt_l + ao + 4 * DSTR);
+            const unsigned po = (kk * TL::PW + half * 8 + kpix) * PSTR;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint4 bh = tr_pair(patch_h + po + tapoff[j], patch_h + po + tapoff[j] + 4 * PSTR);
+                const uint4 bl = tr_pair(patch_l + po + tapoff[j], patch_l + po + tapoff[j] + 4 * PSTR);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afh), __builtin_bit_cast(bf16x8, bh), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afh), __builtin_bit_cast(bf16x8, bl), acc[j], 0, 0, 0);
+                if (TERMS == 3)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afl), __builtin_bit_cast(bf16x8, bh), acc[j], 0, 0, 0);
+            }
+        }
+    }
+#undef LOAD_CHUNK
+#undef STORE_CHUNK
+
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem) + (size_t)wm * 20 * 64 + lane;           // [wm][j][quad][lane]
+    if (kpar == 1) {
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                red[(j * 4 + qd) * 64] = make_float4(acc[j][4 * qd], acc[j][4 * qd + 1], acc[j][4 * qd + 2], acc[j][4 * qd + 3]);
+    }
+    __syncthreads();
+    if (kpar == 0) {
+        const int ci = l31 & 15;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int tap = 2 * j + (l31 >> 4);
+            float* pt = a.partial + (((size_t)split * 9 + tap) * C + wm * 32 + 4 * half) * 16 + ci;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const float4 o = red[(j * 4 + qd) * 64];
+                if (tap < 9) {
+                    pt[(8 * qd + 0) * 16] = acc[j][4 * qd + 0] + o.x;
+                    pt[(8 * qd + 1) * 16] = acc[j][4 * qd + 1] + o.y;
+                    pt[(8 * qd + 2) * 16] = acc[j][4 * qd + 2] + o.z;
+                    pt[(8 * qd + 3) * 16] = acc[j][4 * qd + 3] + o.w;
+                }
+            }
+        }
+    }
+}
+
 // dw[co][ci][tap] (OIHW f32, ci < Cin_real) = sum_s partial[s][tap][co][ci].
 // Block = SL split lanes x (256/SL) (co,ci) pairs: reads are coalesced along ci, the SL lanes walk the
 // splits in parallel (fixed order -> deterministic), an LDS tree combines them, and each pair's nine taps
@@ -900,7 +1087,8 @@ extern "C" int bdn_conv3x3_wgrad(int dtype, const void* dz, int Cout,
 // The first layer's weight gradient straight from dA and z (BatchNorm+ReLU backward applied while staging; `sums` from
 // bdn_bn_bwd_finalize).  Returns BDN_E_SHAPE outside its shape class -- ask bdn_conv3x3_wgrad_bnbwd_supported first.
 extern "C" int bdn_conv3x3_wgrad_bnbwd_supported(int dtype, int N, int H, int W, int Cout, int C0, int imgs_per_group) {
-    if (dtype != BDN_BF16 || Cout != 64 || C0 != 16 || N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group) return 0;
+    if ((dtype != BDN_BF16 && dtype != BDN_BF16X3 && dtype != BDN_BF16X2) || Cout != 64 || C0 != 16 || N <= 0 || H <= 0 || W <= 0 ||
+        imgs_per_group <= 0 || N % imgs_per_group) return 0;
     if (pick_tile(N, H, W, imgs_per_group).TI != 1) return 0;
     return (size_t)N * H * W * 64 < ((size_t)1 << 31) ? 1 : 0;
 }
@@ -910,16 +1098,37 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
                                        float* partial, float* dw_oihw, int Cin_real, int N, int H, int W, void* stream) {
     if (!dA || !z || !bn || !sums || !in0 || !partial || !dw_oihw) BDN_FAIL(BDN_E_ARG, "wgrad_bnbwd: null pointer");
     if (!bdn_conv3x3_wgrad_bnbwd_supported(dtype, N, H, W, Cout, C0, imgs_per_group))
-        BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: only bf16, Cout=64, C0=16, 8x16 tiles (got dtype %d Cout %d C0 %d)", dtype, Cout, C0);
+        BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: only bf16 / bf16x3 / bf16x2, Cout=64, C0=16, 8x16 tiles (got dtype %d Cout %d C0 %d)", dtype, Cout, C0);
     if (ldA < 64 || ldA % 8 || Cin_real <= 0 || Cin_real > 16) BDN_FAIL(BDN_E_SHAPE, "wgrad_bnbwd: bad ldA=%d / Cin_real=%d", ldA, Cin_real);
     // runs at the very end of backward on the MAIN stream (two blocks per CU, nothing of the chain left): its own grid of 512
-    const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, 0, imgs_per_group, BDN_IN_PLAIN, BDN_WG_FLAGS(0, 0, 256));
+    const WgPlan p = wgrad_plan(BDN_BF16, N, H, W, Cout, C0, 0, imgs_per_group, BDN_IN_PLAIN, BDN_WG_FLAGS(0, 0, 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype != BDN_BF16) {
+        // float32 dA [.., ldA] and z [.., 64]; in0 = the first convolution's split operand [N,H,W,32] bf16 = hi(16) | lo(16)
+        WgFirstX3Args x;
+        x.dA = (const float*)dA; x.ldA = ldA; x.z = (const float*)z; x.bn = bn; x.sums = sums; x.xs = (const bf16s*)in0;
+        x.partial = partial; x.N = N; x.H = H; x.W = W; x.imgs_per_group = imgs_per_group;
+        x.tiles_y = p.g.tiles_y; x.tiles_x = p.g.tiles_x; x.n_mtiles = p.g.n_mtiles; x.S = p.S; x.per_split = p.per_split;
+        x.invM = 1.f / (float)((size_t)imgs_per_group * H * W);
+        if (dtype == BDN_BF16X3) {
+            auto kern = wgrad_first_x3_kernel<3>;
+            BDN_SET_SMEM_ONCE(kern, WgFX::SMEM, "wgrad_first_x3");
+            hipLaunchKernelGGL(kern, dim3(p.S), dim3(256), WgFX::SMEM, st, x);
+        } else {
+            auto kern = wgrad_first_x3_kernel<2>;
+            BDN_SET_SMEM_ONCE(kern, WgFX::SMEM, "wgrad_first_x3");
+            hipLaunchKernelGGL(kern, dim3(p.S), dim3(256), WgFX::SMEM, st, x);
+        }
+        BDN_CHECK_LAUNCH("wgrad_first_x3");
+        launch_wgrad_reduce(partial, dw_oihw, p.S, Cout, C0, Cin_real, st);
+        BDN_CHECK_LAUNCH("wgrad_reduce");
+        return BDN_OK;
+    }
     WgFirstArgs a;
     a.dA = (const bf16s*)dA; a.ldA = ldA; a.z = (const bf16s*)z; a.bn = bn; a.sums = sums; a.x = (const bf16s*)in0;
     a.partial = partial; a.N = N; a.H = H; a.W = W; a.imgs_per_group = imgs_per_group;
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles; a.S = p.S; a.per_split = p.per_split;
     a.invM = 1.f / (float)((size_t)imgs_per_group * H * W);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(wgrad_first_kernel, dim3(p.S), dim3(256), WgF::SMEM, st, a);
     BDN_CHECK_LAUNCH("wgrad_first");
     launch_wgrad_reduce(partial, dw_oihw, p.S, Cout, C0, Cin_real, st);

@@ -154,8 +154,8 @@ class Workspace:
         self._chain2 = None        # (stats, bnws) of the second forward chain, allocated when the two-chain forward first runs
         self.n_bnb, self.n_wg = n_bnb, n_wg
         L1 = eng.layers[0]                                # the first conv's fused weight-gradient GEMM runs beside another layer's
-        self.n_wg1 = max(lib.bdn_wgrad_workspace_bytes_ex(eng.dt, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, blocks)) // 4
-                         for blocks in (0, 256, 512))      # (0 / 512: the plain GEMM when it runs on the chain's stream, engine.last_wgrad_on_chain)
+        self.n_wg1 = max(lib.bdn_wgrad_workspace_bytes_ex(dt_, 2 * B, H, W, L1.cout, L1.cin, 0, B, IN_PLAIN, wg_flags(3, 0, blocks)) // 4
+                         for blocks in (0, 256, 512) for dt_ in ((eng.dt, BDN_BF16) if eng.x3 else (eng.dt,)))      # (0 / 512: the plain GEMM when it runs on the chain's stream, engine.last_wgrad_on_chain)
         self._bwd = None
         self._split = {}
         self._outc_ws = None
@@ -276,6 +276,9 @@ class BiDateEngine:
         # the first convolution's weight gradient (the last GEMM of a backward pass, where the bf16 path runs its fused first-layer kernel on the chain's
         # stream) is launched on the chain's stream instead of behind the previous layer's GEMM on the second queue (fp32 / bf16x3 settings)
         self.last_wgrad_on_chain = True
+        # the first convolution's weight gradient with its BatchNorm backward applied on load (bdn_conv3x3_wgrad_bnbwd: bf16 since round 2,
+        # bf16x3 / bf16x3-fast since round 6); False = bn_bwd_apply + the generic GEMM (the checker of the fused form in tests)
+        self.first_wgrad_fused = True
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
@@ -1007,14 +1010,21 @@ class BiDateEngine:
                 dzb = bn_bwd(Lb, ptr(dAb), ck, 2 * B, B, fused_rows=rows_b)
                 wgrad(Lb, dzb, ws.z[La.name], Lb.cin, None, 0, IN_BNRELU, ws.bn[La.name], 2 * B, B)
                 dAa, rows = dgrad(Lb, dzb, 2 * B, B, prev=La)
-            if k == 1 and _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.mdt, 2 * B, hk, wk, La.cout, La.cin, B):
+            if k == 1 and self.first_wgrad_fused and _lib.load().bdn_conv3x3_wgrad_bnbwd_supported(self.mdt, 2 * B, hk, wk, La.cout, La.cin, B):
                 # the first conv has no data gradient: its dz has one reader, so the BatchNorm backward is applied inside
                 # that weight-gradient GEMM's staging and the largest tensor of the step is never written (on the main
-                # stream: nothing of the chain is left to run, the side stream is still busy with e1b's GEMM)
+                # stream: nothing of the chain is left to run, the side stream is still busy with e1b's GEMM).
+                # bf16x3 (round 6): float32 dA and z, the kernel splits dz into bf16 hi + lo in its staging and takes the input's split
+                # operand the forward left; terms of the split product as engine.x3_bwd_terms
                 call('bdn_bn_bwd_finalize', ptr(ws.bn[La.name]), 2, La.cout, ptr(ws.stats), rows, 1, ptr(sc['sums']),
                      ptr(grads[f'{La.bn}.weight']), ptr(grads[f'{La.bn}.bias']), ptr(ws.bnws), st)
-                wargs = (self.dt, ptr(dAa), La.cout, ptr(ws.z[La.name]), ptr(ws.bn[La.name]), ptr(sc['sums']), B, La.cout,
-                         ptr(ws.x0), La.cin, ptr(sc['wg1']), ptr(grads[f'{La.conv}.weight']), La.cin_real, 2 * B, hk, wk, st)
+                if self.x3:
+                    fdt = BDN_BF16X2 if self.x3_bwd_terms == 2 else BDN_BF16X3
+                    fin = ws.split_buf(('a', La.name), 2 * B * hk * wk * 2 * La.cin)
+                else:
+                    fdt, fin = self.dt, ws.x0
+                wargs = (fdt, ptr(dAa), La.cout, ptr(ws.z[La.name]), ptr(ws.bn[La.name]), ptr(sc['sums']), B, La.cout,
+                         ptr(fin), La.cin, ptr(sc['wg1']), ptr(grads[f'{La.conv}.weight']), La.cin_real, 2 * B, hk, wk, st)
                 if not self._diag_skip_wgrad:
                     if self.prof is not None and (self.prof_filter is None or 'wgrad_first_kernel' in self.prof_filter):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

