@@ -205,7 +205,11 @@ int bdn_conv3x3_wgrad_variant(int dtype, int N, int H, int W, int Cout, int C0, 
  * so dz = bn_bwd(dA, z) is never written -- the kernel reads dA [N,H,W,ldA>=64] and z [N,H,W,64], applies
  * bdn_bn_bwd_apply's expression with `sums` from bdn_bn_bwd_finalize, rounds to bf16 and multiplies with the input patches
  * in0 [N,H,W,16].  The result equals bdn_bn_bwd_apply + bdn_conv3x3_wgrad up to the summation order of the partial tiles.
- * Shape class: bf16, Cout = 64, C0 = 16 (bdn_conv3x3_wgrad_bnbwd_supported); partial: bdn_wgrad_workspace_bytes(). */
+ * Shape class: Cout = 64, C0 = 16 (bdn_conv3x3_wgrad_bnbwd_supported); partial: bdn_wgrad_workspace_bytes().
+ * dtype BDN_BF16X3 / BDN_BF16X2 (round 6): dA [N,H,W,ldA] and z [N,H,W,64] float32, in0 = the input's split operand [N,H,W,32] bf16 =
+ * hi(16) | lo(16) (bdn_pack_input(BDN_BF16X3) / bdn_split_pack); dz is formed in float32, split into bf16 hi + lo inside the staging and the
+ * three (two: dz rounded) terms of the split product go into one accumulator: equals bdn_bn_bwd_apply_split + bdn_conv3x3_wgrad(dtype) up to
+ * summation order, without the pass over dA and z and without the split dz. */
 int bdn_conv3x3_wgrad_bnbwd_supported(int dtype, int N, int H, int W, int Cout, int C0, int imgs_per_group);
 int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const void* z, const float* bn, const float* sums,
                             int imgs_per_group, int Cout, const void* in0, int C0,
