@@ -818,7 +818,7 @@ class BiDateEngine:
                 # (per-layer buffers: the weight-gradient stream may still read one while the chain splits the next layer's)
                 sd = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)
                 sw = ws.split_buf(('a', L.name), n * hk * wk * 2 * (c0 + c1))
-                flg = wg_flags(3, 0, self.wgrad_blocks)
+                flg = wg_flags(1 if self._diag_skip_reduce else 3, 0, self.wgrad_blocks)      # (_diag_skip_reduce: timing diagnostics only)
                 xdt = BDN_BF16X2 if self.x3_bwd_terms == 2 else BDN_BF16X3
                 nb = lib.bdn_wgrad_workspace_bytes_ex(xdt, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, flg)
                 part = ws.split_buf(part_key, nb // 2)        # ('p1': the one GEMM that runs on the chain's stream beside the queue's own)
