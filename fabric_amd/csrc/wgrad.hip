@@ -536,6 +536,10 @@ struct WgFirstArgs {
     int N, H, W, imgs_per_group;
     int tiles_y, tiles_x, n_mtiles, S, per_split;
     float invM;
+    // z == nullptr: dA IS dz (no BatchNorm backward on load).  Dz > 0 (bdn_conv3d_wgrad, 16-channel inputs): the N images are depth slices of
+    // N / Dz samples and this launch is depth tap dshift + 1 -- dz of slice n pairs with the input slice n + dshift; a partner outside the
+    // sample contributes nothing (its patch is staged as zeros)
+    int Dz, dshift;
 };
 struct WgF {
     using TL = Tile<8, 16, 1>;
@@ -547,6 +551,8 @@ struct WgF {
     static constexpr int SMEM = (PATCH_BYTES + DZ_BYTES) > RED_BYTES ? (PATCH_BYTES + DZ_BYTES) : RED_BYTES;
 };
 
+// P3: the plain-dz / depth-tap form (see WgFirstArgs); false = the 2-D training kernel, compiled without those branches
+template <bool P3>
 __global__ __launch_bounds__(256, 2) void wgrad_first_kernel(WgFirstArgs a) {
     using TL = WgF::TL;
     constexpr int C = 64, PSTR = WgF::PSTR, DSTR = WgF::DSTR;
@@ -578,26 +584,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_first_kernel(WgFirstArgs a) {
         const int tx_ = (q_) % a.tiles_x, ty_ = ((q_) / a.tiles_x) % a.tiles_y, n_ = (q_) / (a.tiles_x * a.tiles_y); \
         const int y0_ = ty_ * 8, x0_ = tx_ * 16;                                                        \
         grp_next = n_ / a.imgs_per_group; ok = 0;                                                       \
+        const bool pv_ = !P3 || (unsigned)(n_ % a.Dz + a.dshift) < (unsigned)a.Dz;   /* 3x3x3: the partner slice lies inside the sample */ \
+        const int np_ = P3 ? n_ + (pv_ ? a.dshift : 0) : n_;                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                  \
             const int slot = (tid + i * 256) >> 3, y = y0_ + (slot >> 4), x = x0_ + (slot & 15);         \
             const bool ok_ = y < a.H && x < a.W;                                                         \
             const size_t pix = ((size_t)n_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);             \
             gq[i] = *reinterpret_cast<const uint4*>(a.dA + pix * a.ldA + c8);                            \
-            zq[i] = *reinterpret_cast<const uint4*>(a.z + pix * C + c8);                                 \
+            if (!P3) zq[i] = *reinterpret_cast<const uint4*>(a.z + pix * C + c8);             \
             ok |= (ok_ ? 1u : 0u) << i;                                                                  \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
             const int u = tid + i * 256, pp = u >> 1, yy = pp / TL::PW, xx = pp % TL::PW;                \
             const int y = y0_ + yy - 1, x = x0_ + xx - 1;                                                \
-            const bool ok_ = u < TL::NPIX * 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
-            const size_t pix = ((size_t)n_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);             \
+            const bool ok_ = pv_ && u < TL::NPIX * 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W; \
+            const size_t pix = ((size_t)np_ * a.H + (ok_ ? y : y0_)) * a.W + (ok_ ? x : x0_);            \
             pq[i] = *reinterpret_cast<const uint4*>(a.x + pix * 16 + (u & 1) * 8);                       \
             ok |= (ok_ ? 1u : 0u) << (8 + i);                                                            \
         }                                                                                               \
     }
 #define STORE_CHUNK()                                                                                    \
     {                                                                                                   \
-        if (grp_next != grp_cur) {                                                                      \
+        if (!P3 && grp_next != grp_cur) {                                                    \
             grp_cur = grp_next;                                                                         \
             _Pragma("unroll") for (int e = 0; e < 8; e++) {                                              \
                 mean[e] = bn_row(a.bn, grp_cur, 0, C)[c8 + e]; inv[e] = bn_row(a.bn, grp_cur, 1, C)[c8 + e]; \
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_first_kernel(WgFirstArgs a) {
                 const float xhat = (fz[e] - mean[e]) * inv[e];                                          \
                 o[e] = sc[e] * (gm - k0[e] - xhat * k1[e]);                                             \
             }                                                                                           \
-            uint4 v_ = Unit<bf16s>::pack(o);                                                             \
+            uint4 v_ = !P3 ? Unit<bf16s>::pack(o) : gq[i];      /* plain mode: dA is dz already */ \
             const bool ok_ = (ok >> i) & 1u;                                                             \
             v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
             *reinterpret_cast<uint4*>(dzt + ((tid + i * 256) >> 3) * DSTR + (tid & 7) * 16) = v_;        \
@@ -1129,7 +1137,8 @@ extern "C" int bdn_conv3x3_wgrad_bnbwd(int dtype, const void* dA, int ldA, const
     a.partial = partial; a.N = N; a.H = H; a.W = W; a.imgs_per_group = imgs_per_group;
     a.tiles_y = p.g.tiles_y; a.tiles_x = p.g.tiles_x; a.n_mtiles = p.g.n_mtiles; a.S = p.S; a.per_split = p.per_split;
     a.invM = 1.f / (float)((size_t)imgs_per_group * H * W);
-    hipLaunchKernelGGL(wgrad_first_kernel, dim3(p.S), dim3(256), WgF::SMEM, st, a);
+    a.Dz = 0; a.dshift = 0;
+    hipLaunchKernelGGL(wgrad_first_kernel<false>, dim3(p.S), dim3(256), WgF::SMEM, st, a);
     BDN_CHECK_LAUNCH("wgrad_first");
     launch_wgrad_reduce(partial, dw_oihw, p.S, Cout, C0, Cin_real, st);
     BDN_CHECK_LAUNCH("wgrad_reduce");
@@ -1167,6 +1176,26 @@ extern "C" int bdn_conv3d_wgrad(int dtype, const void* dz, int Cout, const void*
     const int NS = N * D;
     const WgPlan p = wgrad_plan(dtype, NS, H, W, Cout, C, 0, 1 /* one slice per tile */, BDN_IN_PLAIN, 0);
     if (p.g.TI != 1) BDN_FAIL(BDN_E_SHAPE, "conv3d_wgrad: internal plan error");
+    if (dtype == BDN_BF16 && Cout == 64 && C == 16 && (size_t)NS * H * W * 64 < ((size_t)1 << 31)) {
+        // the first layer of a multi-date stack (13 -> 64): the 2-D first-layer kernel in its plain-dz form, once per depth tap -- 64 x 16 x 9
+        // accumulators per block, HBM-bound (dz is read three times, 4.6 TB/s) where the generic k-split GEMM ran at 1.6 TB/s
+        WgFirstArgs f;
+        f.dA = (const bf16s*)dz; f.ldA = Cout; f.z = nullptr; f.bn = nullptr; f.sums = nullptr; f.x = (const bf16s*)in;
+        f.partial = partial; f.N = NS; f.H = H; f.W = W; f.imgs_per_group = 1;
+        f.tiles_y = p.g.tiles_y; f.tiles_x = p.g.tiles_x; f.n_mtiles = p.g.n_mtiles; f.S = p.S * (p.ksplit ? 2 : 1);
+        f.per_split = (p.g.n_mtiles + f.S - 1) / f.S;
+        f.S = (p.g.n_mtiles + f.per_split - 1) / f.per_split;      // no empty splits (their partial tiles would be read uninitialised)
+        f.invM = 0.f; f.Dz = D;
+        hipStream_t st1 = reinterpret_cast<hipStream_t>(stream);
+        for (int kd = 0; kd < 3; kd++) {
+            f.dshift = kd - 1;
+            hipLaunchKernelGGL(wgrad_first_kernel<true>, dim3(f.S), dim3(256), WgF::SMEM, st1, f);
+            BDN_CHECK_LAUNCH("conv3d_wgrad_first");
+            launch_wgrad_reduce(partial, dw_oidhw, f.S, Cout, C, Cin_real, st1, 27, 9 * kd);
+            BDN_CHECK_LAUNCH("conv3d_wgrad_reduce");
+        }
+        return BDN_OK;
+    }
     WgradArgs a;
     a.dz = dz; a.Cout = Cout; a.in0 = in; a.in1 = nullptr; a.C0 = C; a.C1 = 0; a.in_bn = nullptr; a.imgs_per_group = 1;
     a.partial = partial; a.N = NS; a.H = H; a.W = W;

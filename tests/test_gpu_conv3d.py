@@ -16,7 +16,7 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
-CASES = [(2, 5, 16, 16, 13, 64), (1, 3, 11, 37, 64, 64), (2, 5, 24, 32, 64, 128), (1, 1, 16, 16, 64, 64), (3, 2, 8, 8, 128, 64),
+CASES = [(2, 5, 16, 16, 13, 64), (1, 3, 11, 37, 13, 64), (3, 1, 24, 40, 13, 64), (1, 3, 11, 37, 64, 64), (2, 5, 24, 32, 64, 128), (1, 1, 16, 16, 64, 64), (3, 2, 8, 8, 128, 64),
          (1, 4, 19, 23, 192, 128)]
 
 
