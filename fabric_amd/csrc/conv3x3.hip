@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256, (!BB && sizeof(TO) == sizeof(T) && ((ONE && BN
     constexpr bool BRANCHFREE = !ONE;
     static_assert(!BB || (sizeof(T) == 2 && sizeof(TO) == 2 && !D3 && TI == 1), "BatchNorm backward on load: bf16 2-D launches, one image per tile");
     static_assert(!EV || (!BB && !D3 && sizeof(T) == sizeof(TO)), "eval-mode epilogue: plain 2-D launches");
-    static_assert(X3 == 0 || ((X3 == 2 || X3 == 3) && sizeof(T) == 2 && sizeof(TO) == 4 && CKB == 128 && !ONE && !D3 && !BB && !EV), "fused split product: bf16 operands, float32 outputs");
+    static_assert(X3 == 0 || ((X3 == 2 || X3 == 3) && sizeof(T) == 2 && sizeof(TO) == 4 && (CKB == 128 || CKB == 32) && !ONE && !D3 && !BB && !EV), "fused split product: bf16 operands, float32 outputs");
+    static_assert(!XF || CKB == 128, "float32-source staging: 64-channel chunks");
     static_assert(!XF || X3 != 0, "float32-source staging belongs to the fused split product");
     uint4 preg[NPU];
     uint4 pregz[BB ? NPU : 1];                           // BB: the z units of the same pixels
@@ -1018,18 +1019,18 @@ static ConvPlan conv_plan_x3f(int N, int H, int W, int Cout, int imgs_per_group)
     return p;
 }
 
-template <int X3, bool XF = false>
+template <int X3, bool XF = false, int CKB = 128>
 static int dispatch_conv_x3f(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     const TileGeom& g = p.g;
-    if (g.TI == 1 && p.BN == 128) return launch_conv<bf16s, 128, 8, 16, 1, 128, 1, 4, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
-    if (g.TI == 1) return launch_conv<bf16s, 128, 8, 16, 1, 64, 2, 2, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
-    return launch_conv<bf16s, 128, 8, 8, 2, 64, 2, 2, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
+    if (g.TI == 1 && p.BN == 128) return launch_conv<bf16s, CKB, 8, 16, 1, 128, 1, 4, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
+    if (g.TI == 1) return launch_conv<bf16s, CKB, 8, 16, 1, 64, 2, 2, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
+    return launch_conv<bf16s, CKB, 8, 8, 2, 64, 2, 2, false, float, false, false, false, X3, XF>(a, g.n_mtiles, st);
 }
 
-// tiles of a launch by operand type: the bf16x3 kernels with the fused split product (C0 a multiple of 64) have their own tile plan
+// tiles of a launch by operand type: the bf16x3 kernels with the fused split product have their own tile plan
 extern "C" int bdn_conv3x3_num_mtiles_ex(int dtype, int N, int H, int W, int C0, int Cout, int imgs_per_group) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || imgs_per_group <= 0) return 0;
-    if (BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) && C0 % 64 == 0) return conv_plan_x3f(N, H, W, Cout, imgs_per_group).g.n_mtiles;
+    if (BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) && C0 % 16 == 0) return conv_plan_x3f(N, H, W, Cout, imgs_per_group).g.n_mtiles;
     return conv_plan(N, H, W, Cout, imgs_per_group).g.n_mtiles;
 }
 
@@ -1062,7 +1063,7 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
         // BDN_BF16X2: K = [hi | lo] against the first two thirds of every image row -- a_hi*w_hi + a_lo*w_hi
         if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "conv3x3(bf16x3): one split-packed, plain operand (bdn_split_pack does cat / BatchNorm+ReLU)");
         if (C0 % 16) BDN_FAIL(BDN_E_SHAPE, "conv3x3(bf16x3): C0=%d must be a multiple of 16", C0);
-        if (BDN_X3_FUSED && C0 % 64 == 0) { a.in1 = nullptr; a.C0 = C0; a.C1 = 0; a.ld0 = 2 * C0; a.ld1 = 0; a.w_kgroups = 3 * C0 / 16; }     // fused split product (below)
+        if (BDN_X3_FUSED) { a.in1 = nullptr; a.C0 = C0; a.C1 = 0; a.ld0 = 2 * C0; a.ld1 = 0; a.w_kgroups = 3 * C0 / 16; }     // fused split product (below)
         else if (dtype == BDN_BF16X3) { a.in1 = in0; a.C0 = 2 * C0; a.C1 = C0; a.ld0 = a.ld1 = 2 * C0; }
         else { a.in1 = nullptr; a.C0 = 2 * C0; a.C1 = 0; a.ld0 = 2 * C0; a.ld1 = 0; a.w_kgroups = 3 * C0 / 16; }
     }
@@ -1079,11 +1080,12 @@ static int conv3x3_impl(int dtype, const void* in0, int C0, const void* in1, int
     a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     a.ep_scale = a.ep_shift = nullptr; a.ep_mul = nullptr; a.ep_pool = nullptr; a.pair_stride = 0;
     a.cls_w = a.cls_b = nullptr; a.cls_n = 0; a.cls_logits = nullptr; a.cls_mask = nullptr; a.cls_origins = nullptr; a.cls_H = a.cls_W = 0; a.x3_split = nullptr;
-    const bool x3f = BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2) && C0 % 64 == 0;
+    const bool x3f = BDN_X3_FUSED && (dtype == BDN_BF16X3 || dtype == BDN_BF16X2);       // (C0 % 16 == 0 was checked above: 64-channel chunks where C0 allows, else 16)
     const ConvPlan g = x3f ? conv_plan_x3f(N, H, W, Cout, imgs_per_group) : conv_plan(N, H, W, Cout, imgs_per_group);
     a.tiles_y = g.g.tiles_y; a.tiles_x = g.g.tiles_x; a.n_ntiles = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (x3f) return dtype == BDN_BF16X3 ? dispatch_conv_x3f<3>(a, g, st) : dispatch_conv_x3f<2>(a, g, st);
+    if (x3f && C0 % 64 == 0) return dtype == BDN_BF16X3 ? dispatch_conv_x3f<3>(a, g, st) : dispatch_conv_x3f<2>(a, g, st);
+    if (x3f) return dtype == BDN_BF16X3 ? dispatch_conv_x3f<3, false, 32>(a, g, st) : dispatch_conv_x3f<2, false, 32>(a, g, st);
     if (bb_z) {
         if (dtype != BDN_BF16 || C0 != 64 || in1 || in_mode != BDN_IN_PLAIN)
             BDN_FAIL(BDN_E_SHAPE, "conv3x3_dgrad_bb: bf16, one plain source of C0 = 64 channels (got %d)", C0);

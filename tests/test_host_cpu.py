@@ -37,7 +37,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.bdn_conv3x3_num_mtiles(128, 128, 128, 128, 64) == 128 * 16 * 8    # 8x16 tiles
     assert lib.bdn_conv3x3_num_mtiles(128, 8, 8, 512, 64) == 64                   # two 8x8 images per tile
     assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16X3, 128, 128, 128, 64, 64, 64) == 128 * 16 * 8     # fused split product: no 16x16 tiles
-    assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16X3, 128, 128, 128, 16, 64, 64) == 128 * 8 * 8      # 16-channel operand: the K = [hi | lo | hi] kernels
+    assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16X3, 128, 128, 128, 16, 64, 64) == 128 * 16 * 8     # 16-channel operand: the same, 16-channel chunks
     assert lib.bdn_conv3x3_num_mtiles_ex(_lib.BDN_BF16, 128, 128, 128, 64, 64, 64) == 128 * 8 * 8
     assert lib.bdn_wgrad_workspace_bytes(2, 16, 16, 64, 64, 1) > 0
     with pytest.raises(RuntimeError, match='null pointer'):
