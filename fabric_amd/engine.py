@@ -279,6 +279,10 @@ class BiDateEngine:
         # the first convolution's weight gradient with its BatchNorm backward applied on load (bdn_conv3x3_wgrad_bnbwd: bf16 since round 2,
         # bf16x3 / bf16x3-fast since round 6); False = bn_bwd_apply + the generic GEMM (the checker of the fused form in tests)
         self.first_wgrad_fused = True
+        # bf16x3, three-term backward: grid of the LAST GEMM on the second queue (inc's second convolution: 1.3 ms at the end of the step, when the
+        # chain has little left to run beside it).  In-process A/B: 128 (as the others) 14.507 ms, 160 / 192 / 256 / 384 / 512 / 768: -0.3 / -0.5 /
+        # -0.6 / -0.7 / -0.9 / -0.8 %; two-term backward: +-0 (not applied there).  0 = as the others
+        self.x3_tail_wgrad_blocks = 512
         self.wgrad_blocks = 0           # per-call target grid of the weight-gradient GEMM (0 = the library's default: half the CUs)
         self._handoffs = {}             # device index -> reusable device-local events, one per hand-off of a backward pass
         self._diag_skip_wgrad = False
@@ -818,7 +822,8 @@ class BiDateEngine:
                 # (per-layer buffers: the weight-gradient stream may still read one while the chain splits the next layer's)
                 sd = ws.split_buf(('d', L.name), n * hk * wk * 2 * L.cout)
                 sw = ws.split_buf(('a', L.name), n * hk * wk * 2 * (c0 + c1))
-                flg = wg_flags(1 if self._diag_skip_reduce else 3, 0, self.wgrad_blocks)      # (_diag_skip_reduce: timing diagnostics only)
+                blk_ = self.x3_tail_wgrad_blocks if (L.name == 'e1b' and self.x3_tail_wgrad_blocks and self.x3_bwd_terms == 3) else self.wgrad_blocks
+                flg = wg_flags(1 if self._diag_skip_reduce else 3, 0, blk_)      # (_diag_skip_reduce: timing diagnostics only)
                 xdt = BDN_BF16X2 if self.x3_bwd_terms == 2 else BDN_BF16X3
                 nb = lib.bdn_wgrad_workspace_bytes_ex(xdt, n, hk, wk, L.cout, c0 + c1, 0, ipg, IN_PLAIN, flg)
                 part = ws.split_buf(part_key, nb // 2)        # ('p1': the one GEMM that runs on the chain's stream beside the queue's own)
