@@ -511,6 +511,186 @@ __global__ __launch_bounds__(512, 1) void wgrad7_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad7x (round 6): the bf16x3 / bf16x2 weight gradient with the terms of the split product summed in ONE accumulator.
+// Operands: dz [N,H,W,2 Cout] and in0 [N,H,W,2 Cin] bf16 = hi | lo (bdn_split_pack's layout); a.Cout / a.C0 are the LOGICAL widths.  A block owns
+// a 64 (co) x 64 (ci) tile of the LOGICAL weight gradient and, per 128-pixel chunk, stages FOUR slabs -- patch_hi, dz_hi, patch_lo, dz_lo
+// (TERMS = 2: no dz_lo) -- by LDS-DMA; every (tile row, tap) then issues
+//     acc += dz_hi a_hi;  acc += dz_hi a_lo;  [acc += dz_lo a_hi]
+// Against wgrad7 on the doubled operands (three 64 x 64 tiles of [2 Cout] x [2 Cin], one term each): 20 DMA pieces and 76 fragment reads feed 216
+// MFMAs instead of 30 / 114, the partial tiles are [Cout][Cin] (a quarter), and the reduction writes dw directly -- no [2 Cout][2 Cin][9] tile, no
+// quadrant-sum launch.  LDS: TWO chunk buffers of 80 KB (64 KB for two terms): the DMA of chunk q + 1 is issued behind the barrier that hands
+// chunk q to the consumers and has the 216 MFMAs of chunk q (~3.3 us) to land.
+template <int TERMS>
+__global__ __launch_bounds__(512, 1) void wgrad7x_kernel(WgradArgs a) {
+    constexpr int PW = Wg6::PW, STR = Wg6::STR, BUF = Wg6::BUF, PATCH_BYTES = Wg6::PATCH_BYTES;
+    constexpr unsigned XBUF = TERMS == 3 ? 2 * BUF : BUF + PATCH_BYTES;          // [patch_hi | dz_hi | patch_lo | dz_lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.n_tiles;
+    const int tile = logical % ntile, split = logical / ntile;
+    const int cot_ = tile / a.n_cit, cit_ = tile % a.n_cit;
+    const int co0 = cot_ * 64, ci0 = cit_ * 64;
+    const int Cin = a.C0;                                      // logical widths; pixel strides are 2 Cin / 2 Cout elements
+    const int q_begin = split * a.per_split;
+    const int q_end = min(a.n_mtiles, q_begin + a.per_split);
+    if (q_begin >= q_end) return;
+
+    if (wave >= 4) {
+        // ================================================= producer: 20 (16) LDS-DMA pieces per chunk and wave
+        const int pw = wave - 4;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.in0);
+        const unsigned char* dzp = reinterpret_cast<const unsigned char*>(a.dz);
+        const int Ps = 2 * Cin, Ds = 2 * a.Cout;               // pixel strides in elements
+        const int u_pix = pw * 8 + (lane >> 3), sub = lane & 7;
+        const int swz = ((u_pix >> 1) & 1) << 2;
+        const int unit = sub ^ swz;
+        int pyx[6];
+        unsigned poff_dma[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int pix = u_pix + 32 * i, yy = pix / PW, xx = pix % PW;
+            pyx[i] = pix < Wg6::PH * PW ? (((yy - 1) << 16) | ((xx - 1) & 0xffff)) : (-4096 << 16);
+            poff_dma[i] = (unsigned)(((yy * a.W + xx) * Ps + ci0 + unit * 8) * 2);
+        }
+        const unsigned p_lo = (unsigned)(Cin * 2), d_lo = (unsigned)(a.Cout * 2);       // byte offset of the lo half inside a pixel
+        const int dpx = u_pix & 15, dpy0 = u_pix >> 4;
+        const unsigned drow2 = (unsigned)(2 * a.W * Ds * 2);
+        const unsigned doff0 = (unsigned)(((dpy0 * a.W + dpx) * Ds + co0 + unit * 8) * 2);
+        const unsigned lds_piece0 = (unsigned)(pw * 8 * STR);
+        const unsigned smem_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+        int lq = q_begin;
+        int ltx = q_begin % a.tiles_x, lty = (q_begin / a.tiles_x) % a.tiles_y, ln = q_begin / (a.tiles_x * a.tiles_y);
+        bool c_live = false; int c_y0 = 0, c_x0 = 0; long c_pix = 0;
+#define X7_CUR()                                                                                         \
+        {                                                                                               \
+            c_live = lq < q_end;                                                                        \
+            c_y0 = lty * 8; c_x0 = ltx * 16;                                                            \
+            if (c_live) {                                                                               \
+                c_pix = (long)(ln * a.H + c_y0) * a.W + c_x0;                                           \
+                lq++;                                                                                   \
+                if (++ltx == a.tiles_x) { ltx = 0; if (++lty == a.tiles_y) { lty = 0; ln++; } }         \
+            }                                                                                           \
+        }
+#define X7_DMA(wb_)                                                                                      \
+        {                                                                                               \
+            const u32x4_t rp_ = raw_rsrc(src + (c_pix - a.W - 1) * Ps * 2, Wg6::NUM_RECORDS);           \
+            const u32x4_t rd_ = raw_rsrc(dzp + c_pix * Ds * 2, Wg6::NUM_RECORDS);                       \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) {                                              \
+                const int y_ = c_y0 + (pyx[i] >> 16), x_ = c_x0 + (short)(pyx[i] & 0xffff);             \
+                const bool ok_ = c_live && (unsigned)y_ < (unsigned)a.H && (unsigned)x_ < (unsigned)a.W; \
+                lds_dma16(rp_, smem_base + (wb_) + lds_piece0 + i * 32 * STR, ok_ ? poff_dma[i] : Wg6::OOB); \
+                lds_dma16(rp_, smem_base + (wb_) + BUF + lds_piece0 + i * 32 * STR, ok_ ? poff_dma[i] + p_lo : Wg6::OOB); \
+            }                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                              \
+                const bool ok_ = c_live && (c_y0 + dpy0 + 2 * i) < a.H && (c_x0 + dpx) < a.W;           \
+                lds_dma16(rd_, smem_base + (wb_) + PATCH_BYTES + lds_piece0 + i * 32 * STR, ok_ ? doff0 + (unsigned)i * drow2 : Wg6::OOB); \
+                if (TERMS == 3)                                                                         \
+                    lds_dma16(rd_, smem_base + (wb_) + BUF + PATCH_BYTES + lds_piece0 + i * 32 * STR, ok_ ? doff0 + (unsigned)i * drow2 + d_lo : Wg6::OOB); \
+            }                                                                                           \
+        }
+        X7_CUR() X7_DMA(0)
+        unsigned nxt = XBUF;
+        for (int q = q_begin; q < q_end; q++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk q has landed (nothing else of this wave is in flight)
+            __builtin_amdgcn_s_barrier();                          // ... the consumers take it; they are done with the other buffer
+            asm volatile("" ::: "memory");
+            X7_CUR() X7_DMA(nxt)                                   // chunk q + 1 (past the end: all-zero pieces)
+            nxt = nxt == XBUF ? 0 : XBUF;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef X7_CUR
+#undef X7_DMA
+        return;
+    }
+
+    // ===================================================== consumer
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    const int chan_b = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int kpix = (lane & 15) >> 2;
+    const unsigned a_base = PATCH_BYTES + (half * 8 + kpix) * STR + ((wm ^ ((kpix >> 1) & 1)) * 64) + chan_b;
+    const unsigned b_lin = (half * 8 + kpix) * STR + chan_b;
+    const unsigned b_base0 = b_lin + ((wn ^ (((kpix + 0) >> 1) & 1)) * 64), b_base1 = b_lin + ((wn ^ (((kpix + 1) >> 1) & 1)) * 64);
+    const unsigned b_base2 = b_lin + ((wn ^ (((kpix + 2) >> 1) & 1)) * 64), b_base3 = b_lin + ((wn ^ (((kpix + 3) >> 1) & 1)) * 64);
+#define B_BASE(pr_, c_) ((((c_) + 2 * (pr_)) & 3) == 0 ? b_base0 : (((c_) + 2 * (pr_)) & 3) == 1 ? b_base1 : (((c_) + 2 * (pr_)) & 3) == 2 ? b_base2 : b_base3)
+    uint4 afh[4], afl[TERMS == 3 ? 4 : 1], bqh[2][3], bql[2][3];
+#define TRP(addr_) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr_)))
+#define LDA(dst_, base_, ks_) { const uint2 l_ = TRP((base_) + a_base + (ks_) * 16 * STR), h_ = TRP((base_) + a_base + ((ks_) * 16 + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define LDB(dst_, base_, pr_, c_) { const uint2 l_ = TRP((base_) + B_BASE(pr_, c_) + ((pr_) * PW + (c_)) * STR), h_ = TRP((base_) + B_BASE(pr_, c_) + ((pr_) * PW + (c_) + 4) * STR); dst_ = make_uint4(l_.x, l_.y, h_.x, h_.y); }
+#define X_MMA(t_, ks_, pr_, c_)                                                                          \
+    {                                                                                                   \
+        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afh[(ks_) & 3]), __builtin_bit_cast(bf16x8, bqh[(pr_) & 1][c_]), acc[t_], 0, 0, 0); \
+        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afh[(ks_) & 3]), __builtin_bit_cast(bf16x8, bql[(pr_) & 1][c_]), acc[t_], 0, 0, 0); \
+        if (TERMS == 3)                                                                                 \
+            acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afl[TERMS == 3 ? (ks_) & 3 : 0]), __builtin_bit_cast(bf16x8, bqh[(pr_) & 1][c_]), acc[t_], 0, 0, 0); \
+    }
+#define X_ROW(pr_)                                                                                       \
+    {                                                                                                   \
+        if ((pr_) + 1 < 10) {                                                                           \
+            LDB(bqh[((pr_) + 1) & 1][0], rb, (pr_) + 1, 0) LDB(bqh[((pr_) + 1) & 1][1], rb, (pr_) + 1, 1) LDB(bqh[((pr_) + 1) & 1][2], rb, (pr_) + 1, 2) \
+            LDB(bql[((pr_) + 1) & 1][0], rl, (pr_) + 1, 0) LDB(bql[((pr_) + 1) & 1][1], rl, (pr_) + 1, 1) LDB(bql[((pr_) + 1) & 1][2], rl, (pr_) + 1, 2) \
+        }                                                                                               \
+        if ((pr_) + 1 < 8) { LDA(afh[((pr_) + 1) & 3], rb, (pr_) + 1) if (TERMS == 3) LDA(afl[TERMS == 3 ? ((pr_) + 1) & 3 : 0], rl, (pr_) + 1) } \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((pr_) < 8) { X_MMA(0, (pr_), (pr_), 0) X_MMA(1, (pr_), (pr_), 1) X_MMA(2, (pr_), (pr_), 2) } \
+        if ((pr_) >= 1 && (pr_) < 9) { X_MMA(3, (pr_) - 1, (pr_), 0) X_MMA(4, (pr_) - 1, (pr_), 1) X_MMA(5, (pr_) - 1, (pr_), 2) } \
+        if ((pr_) >= 2) { X_MMA(6, (pr_) - 2, (pr_), 0) X_MMA(7, (pr_) - 2, (pr_), 1) X_MMA(8, (pr_) - 2, (pr_), 2) } \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+    unsigned cur = 0;
+    for (int q = q_begin; q < q_end; q++) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char* rb = smem + cur;
+        const unsigned char* rl = rb + BUF;
+        LDB(bqh[0][0], rb, 0, 0) LDB(bqh[0][1], rb, 0, 1) LDB(bqh[0][2], rb, 0, 2)
+        LDB(bql[0][0], rl, 0, 0) LDB(bql[0][1], rl, 0, 1) LDB(bql[0][2], rl, 0, 2)
+        LDA(afh[0], rb, 0)
+        if (TERMS == 3) LDA(afl[0], rl, 0)
+        X_ROW(0) X_ROW(1) X_ROW(2) X_ROW(3) X_ROW(4) X_ROW(5) X_ROW(6) X_ROW(7) X_ROW(8) X_ROW(9)
+        cur = cur == XBUF ? 0 : XBUF;
+    }
+#undef TRP
+#undef LDA
+#undef LDB
+#undef B_BASE
+#undef X_MMA
+#undef X_ROW
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+        const unsigned lane_off = (unsigned)((wm * 32 + 4 * half) * Cin + ci);
+        const float* __restrict__ base0 = a.partial + ((size_t)split * 9 * a.Cout + co0) * Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            float* pt = const_cast<float*>(base0) + (size_t)tap * a.Cout * Cin;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                pt[(size_t)((r & 3) + 8 * (r >> 2)) * Cin + lane_off] = acc[tap][r];
+        }
+    }
+}
+
+template <int TERMS>
+static int launch_wgrad7x(const WgradArgs& a, hipStream_t st) {
+    constexpr int SMEM = 2 * (TERMS == 3 ? 2 * Wg6::BUF : Wg6::BUF + Wg6::PATCH_BYTES);
+    auto kern = wgrad7x_kernel<TERMS>;
+    BDN_SET_SMEM_ONCE(kern, SMEM, "wgrad7x");
+    hipLaunchKernelGGL(kern, dim3(a.S * a.n_tiles), dim3(512), SMEM, st, a);
+    BDN_CHECK_LAUNCH("wgrad7x");
+    return BDN_OK;
+}
+
 template <bool USE_BN>
 static int launch_wgrad7(const WgradArgs& a, hipStream_t st) {
     auto kern = wgrad7_kernel<USE_BN>;
@@ -952,6 +1132,9 @@ static void launch_wgrad_reduce(const float* partial, float* dw, int S, int Cout
 //   flags bits 0-1   phases (bdn_conv3x3_wgrad_ex)
 //   flags bits 8-11  kernel override: 0 = the library's choice, BDN_WG_SIMPLE forces the one-chunk-at-a-time kernel
 //   flags bits 16-28 target grid size of the GEMM (0 = default, one block per CU)
+#ifndef BDN_WG_X3_FUSED
+#define BDN_WG_X3_FUSED 1     /* A/B switch of the round (tools/build_lib_variant.sh old "-DBDN_WG_X3_FUSED=0") */
+#endif
 constexpr int WG_SIMPLE_MULT = 2;
 constexpr int WG_X3_SKIP = 1 << 30;          // internal plan flag, see wgrad_plan
 constexpr int WG_X3_TWO = 1 << 29;           // internal plan flag (BDN_BF16X2): only the hi half of dz -- the [lo, hi] quadrant is left out as well
@@ -992,9 +1175,13 @@ extern "C" size_t bdn_wgrad_workspace_bytes_ex(int dtype, int N, int H, int W, i
                                                int in_mode, int flags) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0 || imgs_per_group <= 0) return 0;
     if (dtype == BDN_BF16X3 || dtype == BDN_BF16X2)      // doubled operands ([hi | lo] x [hi | lo]) through the bf16 plan + the [2 Cout][2 Cin][9] tile the quadrants are summed from
-        return bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN,
-                                            flags | WG_X3_SKIP | (dtype == BDN_BF16X2 ? WG_X3_TWO : 0))
-               + (size_t)4 * Cout * (C0 + C1) * 9 * sizeof(float);
+    {
+        const size_t doubled = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * (C0 + C1), 0, imgs_per_group, BDN_IN_PLAIN,
+                                                            flags | WG_X3_SKIP | (dtype == BDN_BF16X2 ? WG_X3_TWO : 0))
+                               + (size_t)4 * Cout * (C0 + C1) * 9 * sizeof(float);
+        const size_t fused = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, Cout, C0 + C1, 0, imgs_per_group, BDN_IN_PLAIN, flags);   // wgrad7x: the logical plan
+        return doubled > fused ? doubled : fused;
+    }
     const WgPlan p = wgrad_plan(dtype, N, H, W, Cout, C0, C1, imgs_per_group, in_mode, flags);
     return (size_t)p.S * (p.ksplit ? 2 : 1) * 9 * Cout * (C0 + C1) * sizeof(float);
 }
@@ -1038,6 +1225,31 @@ extern "C" int bdn_conv3x3_wgrad_ex(int dtype, const void* dz, int Cout,
         if (in1 || in_mode != BDN_IN_PLAIN) BDN_FAIL(BDN_E_ARG, "wgrad(bf16x3): one split-packed, plain operand");
         if (Cout <= 0 || Cout % 32 || C0 <= 0 || C0 % 8 || Cin_real <= 0 || Cin_real > C0)
             BDN_FAIL(BDN_E_SHAPE, "wgrad(bf16x3): Cout=%d must be a multiple of 32, C0=%d of 8, Cin_real=%d <= C0", Cout, C0, Cin_real);
+        if (N <= 0 || H <= 0 || W <= 0 || imgs_per_group <= 0 || N % imgs_per_group)
+            BDN_FAIL(BDN_E_SHAPE, "wgrad(bf16x3): bad N=%d H=%d W=%d imgs_per_group=%d", N, H, W, imgs_per_group);
+        if (BDN_WG_X3_FUSED && Cout % 64 == 0 && C0 % 64 == 0 && (size_t)N * H * W * 2 * (size_t)(Cout > C0 ? Cout : C0) < ((size_t)1 << 31)) {
+            // full 64-channel tiles on 8 x 16 spatial tiles: the terms of the split product in one accumulator (wgrad7x_kernel), the plan of
+            // the LOGICAL [Cout] x [C0] problem, the plain split-K reduction straight into dw
+            const WgPlan pf = wgrad_plan(BDN_BF16, N, H, W, Cout, C0, 0, imgs_per_group, BDN_IN_PLAIN, phases);
+            if (pf.variant == BDN_WG_ROLE) {
+                WgradArgs a;
+                a.dz = dz; a.Cout = Cout; a.in0 = in0; a.in1 = nullptr; a.C0 = C0; a.C1 = 0; a.in_bn = nullptr; a.imgs_per_group = imgs_per_group;
+                a.partial = partial; a.N = N; a.H = H; a.W = W;
+                a.tiles_y = pf.g.tiles_y; a.tiles_x = pf.g.tiles_x; a.n_mtiles = pf.g.n_mtiles;
+                a.S = pf.S; a.per_split = pf.per_split; a.n_cot = pf.n_cot; a.n_cit = pf.n_cit; a.x3h = 0; a.n_tiles = pf.n_tiles;
+                a.Dz = 0; a.dshift = 0;
+                hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+                if (phases & 1) {
+                    const int rc = dtype == BDN_BF16X3 ? launch_wgrad7x<3>(a, st) : launch_wgrad7x<2>(a, st);
+                    if (rc) return rc;
+                }
+                if (phases & 2) {
+                    launch_wgrad_reduce(partial, dw_oihw, pf.S, Cout, C0, Cin_real, st);
+                    BDN_CHECK_LAUNCH("wgrad_reduce");
+                }
+                return BDN_OK;
+            }
+        }
         const size_t gemm_bytes = bdn_wgrad_workspace_bytes_ex(BDN_BF16, N, H, W, 2 * Cout, 2 * C0, 0, imgs_per_group, BDN_IN_PLAIN, phases | xfl);
         float* tile = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(partial) + gemm_bytes);
         const int rc = bdn_conv3x3_wgrad_ex(BDN_BF16, dz, 2 * Cout, in0, 2 * C0, nullptr, 0, BDN_IN_PLAIN, nullptr, imgs_per_group,
