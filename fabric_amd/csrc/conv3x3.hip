@@ -18,6 +18,11 @@
 //     the co-limiter of the LDS-staged version: 96 % busy at 50 % MFMA).
 // Epilogue: + bias, per-tile sum / sum^2 for the following BatchNorm, transpose through LDS, 16-byte
 // coalesced NHWC stores.  Block ids are remapped so the N-tiles of one M-tile share an XCD's L2.
+// Template flags on the same main loop: D3 (3x3x3: three depth sources of one reduction), BB (data gradient with the layer's BatchNorm
+// backward formed while the operand is staged), EV (round 6, eval mode: the epilogue applies the folded running-statistics affine + ReLU and
+// stores the activation; optional date product / 2x2 max-pool / 1x1 classifier + argmax + stitching from the tile in LDS; date-paired
+// tiles), X3 (round 6, bf16x3: hi and lo patches of a chunk in LDS, the terms of the split product into one accumulator) and XF (X3 on a
+// float32 source: BatchNorm+ReLU and the hi / lo split inside the staging).
 #include "common.hpp"
 #include <type_traits>
 #ifndef BDN_X3_FUSED
